@@ -1,0 +1,136 @@
+/* mvd_hip.h -- C ABI of libmvd_hip.so: the MI355X (gfx950) implementation of the
+ * pananananas/MVD denoising hot path.
+ *
+ * The reference has no FFI of its own: its boundary is the Python object protocol of
+ * MultiViewUNet.forward (/root/reference/src/models/mvd_unet.py:179-191) which calls
+ * diffusers' UNet2DConditionModel (mvd_unet.py:318-326, image_encoder.py:105-110),
+ * ImageCrossAttentionProcessor.__call__ (attention.py:48-188) and
+ * CameraEncoder.{encode_cameras,apply_modulation} (camera_encoder.py:160-255).
+ * This header is what a binding for that path binds instead (ctypes stub: INTEGRATION.md).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless its name ends in _host;
+ *  - no torch / C++ types; sizes are explicit; the caller owns every buffer;
+ *  - work is issued asynchronously on the hipStream_t passed as `void* stream`;
+ *  - every function returns 0 on success, <0 on error; mvd_last_error() returns the
+ *    message of the calling thread's last failure;
+ *  - one calling thread per engine handle.
+ */
+#ifndef MVD_HIP_H
+#define MVD_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVD_MAX_LEVELS 4
+
+/* UNet2DConditionModel config subset (diffusers 0.32.2 names; SD-2.1 values in comments).
+ * Replaces: UNet2DConditionModel.from_pretrained(...).config  (mvd_unet.py:46-53). */
+typedef struct {
+  int in_channels;                         /* 4 */
+  int out_channels;                        /* 4 */
+  int num_levels;                          /* 4 */
+  int block_out_channels[MVD_MAX_LEVELS];  /* 320 640 1280 1280 */
+  int num_heads[MVD_MAX_LEVELS];           /* 5 10 20 20 ("attention_head_dim") */
+  int layers_per_block;                    /* 2 */
+  int cross_attention_dim;                 /* 1024 */
+  int norm_num_groups;                     /* 32 */
+  float norm_eps;                          /* 1e-5 */
+  /* MVD wrapper (mvd_unet.py:23-36) */
+  int cam_output_dim;                      /* 1024 */
+  int cam_hidden_dim;                      /* 512 */
+  int simple_cam_encoder;                  /* 0 */
+  float cam_modulation_strength;           /* 0.2 */
+} mvd_config_t;
+
+typedef struct mvd_engine mvd_engine_t;
+
+const char* mvd_last_error(void);
+
+/* ---- engine lifetime -------------------------------------------------------------- */
+int mvd_engine_create(const mvd_config_t* cfg, mvd_engine_t** out);
+int mvd_engine_destroy(mvd_engine_t* e);
+
+/* Packed-weight registration.  `set` 0 = base_unet (+ adapter processors + camera encoder),
+ * 1 = image_encoder.unet.  Slot names and layouts: DESIGN.md "Weight slots".
+ * dtype: 0 = fp32, 1 = bf16.  The engine keeps the pointer; the caller keeps the memory alive.
+ * Replaces: nn.Module.load_state_dict / .to(device) of mvd_unet.py:164-177, infer.py:67-76. */
+int mvd_engine_set_weight(mvd_engine_t* e, int set, const char* slot, const void* ptr, int64_t numel, int dtype);
+int mvd_engine_clear_weights(mvd_engine_t* e, int set);
+
+/* Workspace: bytes needed for one forward at the given shape (dry run of the schedule). */
+int64_t mvd_engine_workspace_bytes(mvd_engine_t* e, int batch, int height, int width, int text_len, int ref_batch);
+/* Persistent bytes for the cached reference K/V (and kept feature maps when keep_features). */
+int64_t mvd_engine_refcache_bytes(mvd_engine_t* e, int ref_batch, int height, int width, int keep_features);
+int mvd_engine_bind_workspace(mvd_engine_t* e, void* ws, int64_t ws_bytes, void* refcache, int64_t refcache_bytes);
+
+/* ---- the hot path ------------------------------------------------------------------ */
+enum {
+  MVD_USE_CAMERA = 1,       /* use_camera_conditioning and target_camera is not None (mvd_unet.py:241) */
+  MVD_USE_IMAGE = 2,        /* use_image_conditioning and source_image_latents is not None (:269)      */
+  MVD_REUSE_REF = 4,        /* reuse reference K/V computed by a previous call (inputs step-invariant)  */
+  MVD_KEEP_FEATURES = 8     /* keep the 16 encoder feature maps for mvd_engine_get_feature               */
+};
+
+/* One MultiViewUNet.forward (mvd_unet.py:179-338).  All tensors fp32, contiguous. */
+typedef struct {
+  int batch;                 /* rows of `sample` (2B under classifier-free guidance)                    */
+  int height, width;         /* latent spatial size (64x64 for 512x512 images)                           */
+  int text_len;              /* 77                                                                       */
+  const float* sample;       /* [batch][in_channels][H][W]                                               */
+  const float* timesteps;    /* [batch] (already expanded; ints as floats)                               */
+  const float* text;         /* [batch][text_len][cross_attention_dim] (already repeated, :233-237)      */
+  const float* source_camera;/* [batch][cam_rows][4] or NULL                                             */
+  const float* target_camera;
+  int cam_rows;              /* 3 or 4 (Q8)                                                              */
+  const float* fourier_proj; /* [cam_output_dim][6*((cam_output_dim/2)/3)] the per-call random matrix Q1 */
+  const float* source_latents;/* [ref_batch][in_channels][H][W] or NULL                                  */
+  const float* encoder_text; /* [ref_batch][text_len][xdim]: text rows chosen per mvd_unet.py:278-285     */
+  int ref_batch;
+  int flags;
+  float* out;                /* [batch][out_channels][H][W]                                              */
+} mvd_forward_args_t;
+
+int mvd_unet_forward(mvd_engine_t* e, const mvd_forward_args_t* args, void* stream);
+
+/* Number / shape / copy-out (NCHW fp32) of the encoder feature maps (image_encoder.py:36-84). */
+int mvd_engine_num_features(mvd_engine_t* e);
+int mvd_engine_feature_shape(mvd_engine_t* e, int idx, int* channels, int* height, int* width);
+int mvd_engine_get_feature(mvd_engine_t* e, int idx, float* out_nchw, void* stream);
+/* Camera embedding of the last forward ([batch][cam_output_dim] fp32), for parity tests. */
+int mvd_engine_get_camera_embedding(mvd_engine_t* e, float* out, void* stream);
+
+/* ---- operator-level entry points (same kernels the engine schedules; used by tests) -- */
+/* out[M][N] = alpha*(A[M][K] . W[N][K]^T + bias + rowvec[m/rows_per_batch]) + res ; bf16 A/W/res */
+int mvd_op_linear(const void* a, const void* a2, int k1, int k2, const void* w, const float* bias, const float* rowvec,
+                  int ld_rowvec, int rows_per_batch, const void* res, float alpha, int geglu, void* out, int out_f32,
+                  int m, int n, int force_cfg, void* stream);
+/* 3x3 conv (pad 1) on NHWC bf16 as implicit GEMM; optional fused 1x1 shortcut on (sc, sc2) */
+int mvd_op_conv3x3(const void* x, int batch, int in_h, int in_w, int cin, int stride, int upsample, const void* w,
+                   const float* bias, const float* rowvec, int ld_rowvec, const void* res, const void* sc, const void* sc2,
+                   int sc_c1, int sc_c2, void* out, int cout, int force_cfg, void* stream);
+int mvd_op_attention(const void* q, const void* k, const void* v, void* o, int batch, int heads, int nq, int nk, int ldq,
+                     int ldk, int ldv, int ldo, float scale, void* stream);
+int mvd_op_groupnorm(const void* x0, const void* x1, int c0, int c1, int batch, int hw, int groups, float eps,
+                     const float* gamma, const float* beta, int silu, void* y, float* ws, void* stream);
+int mvd_op_layernorm(const void* x, int rows, int c, float eps, const float* gamma, const float* beta, void* y,
+                     void* stream);
+int mvd_op_refnorm(const void* x, int batch, int hw, int c, void* y, void* stream);
+int mvd_op_film(const void* x, int batch, int hw, int c, const float* scale, const float* shift, void* y, void* stream);
+int mvd_op_conv_in(const void* x, int batch, int h, int w, int cin, const float* wt, const float* bias, int cout, void* y,
+                   void* stream);
+int mvd_op_conv_out(const void* x, int batch, int h, int w, int c, const void* wt, const float* bias, int cout, float* y,
+                    void* stream);
+int mvd_op_nchw_to_nhwc(const float* x, int batch, int c, int hw, const float* scale, const float* shift, void* y,
+                        void* stream);
+int mvd_op_nhwc_to_nchw(const void* x, int batch, int hw, int c, float* y, void* stream);
+int mvd_op_f32_to_bf16(const float* x, int64_t n, void* y, void* stream);
+int mvd_gemm_num_configs(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

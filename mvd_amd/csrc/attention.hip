@@ -1,0 +1,243 @@
+// Flash-style attention for head_dim 64, bf16 in/out, fp32 softmax+accumulate (gfx950).
+//
+// One launch covers up to two independent problems (e.g. a BasicTransformerBlock's own
+// attention and the MVD adapter's cross-view attention on the same query tokens).
+// Layout: token-major with heads interleaved in the channel dim, q[b][n][head*64 + d],
+// arbitrary row/batch strides so fused QKV GEMM outputs are consumed in place.
+//
+// Structure (per wave: 32 query rows; per workgroup: NW waves sharing K/V tiles in LDS):
+//   S^T = K . Q^T   v_mfma_f32_32x32x16_bf16, A = K rows from LDS (ds_read_b128, XOR
+//                   swizzle), B = Q fragments held in registers for the whole kernel.
+//                   The result has the QUERY on the lane and 32 of the 64 keys of the KV
+//                   tile in the lane's registers -> row max / row sum are in-register
+//                   reductions plus one v_permlane32_swap with the partner half-wave.
+//   O^T += V^T . P^T  the S^T accumulator (converted to bf16) is directly the B operand
+//                   of the second MFMA (k-index permutation of the accumulator layout is
+//                   matched on the V side); V^T fragments come from the row-major V tile
+//                   through ds_read_b64_tr_b16 (hardware transpose read).
+//   online softmax in exp2 domain with the softmax scale folded into one v_fma.
+// K/V tiles (64 keys) are double buffered in LDS; global loads for tile t+1 are issued
+// before the MFMAs of tile t and written after them.
+#include "kernels.h"
+
+namespace {
+
+constexpr int KV_TILE = 64;
+constexpr int TILE_BYTES = KV_TILE * 128;  // 64 keys x 64 dims x 2 B
+constexpr float NEG_BIG = -1.0e30f;
+
+MVD_DEVINL int k_off(int key, int chunk) { return key * 128 + ((chunk ^ ((key >> 1) & 7)) << 4); }
+// V swizzle keeps 64-byte halves intact for the 4x16 transposed reads
+MVD_DEVINL int v_off(int key, int chunk) { return key * 128 + ((chunk ^ (((key >> 1) & 1) << 2)) << 4); }
+
+// Exchange with the partner lane (lane ^ 32).  NOTE: __builtin_bit_cast applied directly to a
+// vector element expression (r[1]) silently reads element 0 with hipcc/ROCm 7.2, so the
+// elements are copied to scalars first.
+MVD_DEVINL float pair_other(float x, float& own) {
+  const unsigned a = __builtin_bit_cast(unsigned, x);
+  auto r = __builtin_amdgcn_permlane32_swap(a, a, false, false);
+  // lanes 0-31: r[0] = own, r[1] = partner ; lanes 32-63: r[0] = partner, r[1] = own
+  const unsigned r0 = r[0], r1 = r[1];
+  own = __builtin_bit_cast(float, r0);
+  return __builtin_bit_cast(float, r1);
+}
+MVD_DEVINL float pair_max(float x) { float o; const float p = pair_other(x, o); return fmaxf(o, p); }
+MVD_DEVINL float pair_sum(float x) { float o; const float p = pair_other(x, o); return o + p; }
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void attn_kernel(const MvdAttnArgs a) {
+  constexpr int NT = 64 * NW;
+  constexpr int QB = 32 * NW;
+  constexpr int LD_IT = (KV_TILE * 8) / NT;  // 16-byte chunks per thread per tile
+  static_assert((KV_TILE * 8) % NT == 0, "tile must divide over threads");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];  // K0 K1 V0 V1
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane & 31, lh = lane >> 5;
+  const int head = blockIdx.y;
+  int bz = blockIdx.z;
+  const int pi = bz / a.batch;
+  bz -= pi * a.batch;
+  const MvdAttnProblem& P = a.p[pi];
+  const int nq = P.nq, nk = P.nk;
+  const int qblk0 = blockIdx.x * QB;
+  if (qblk0 >= nq) return;  // whole workgroup exits together (uniform)
+
+  const bf16_t* qp = P.q + (size_t)bz * P.bsq + head * 64;
+  const bf16_t* kp = P.k + (size_t)bz * P.bsk + head * 64;
+  const bf16_t* vp = P.v + (size_t)bz * P.bsv + head * 64;
+  bf16_t* op = P.o + (size_t)bz * P.bso + head * 64;
+
+  // Q fragments: B operand of S^T = K.Q^T : lane (query lq, half lh) holds Q[q][16*ks + 8*lh .. +7]
+  const int qrow = qblk0 + wave * 32 + lq;
+  const int qrow_c = qrow < nq ? qrow : nq - 1;
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+    qf[ks] = *reinterpret_cast<const bf16x8*>(qp + (size_t)qrow_c * P.ldq + ks * 16 + lh * 8);
+
+  // loader mapping: chunk id -> (key row, 16-byte chunk)
+  const int ld_kc = tid & 7;
+  const int ld_row = tid >> 3;
+  u32x4 rk[LD_IT], rv[LD_IT];
+  auto load_tile = [&](int kb) {
+#pragma unroll
+    for (int i = 0; i < LD_IT; ++i) {
+      const int key = kb * KV_TILE + ld_row + i * (NT / 8);
+      u32x4 zk = {0u, 0u, 0u, 0u}, zv = {0u, 0u, 0u, 0u};
+      if (key < nk) {
+        zk = *reinterpret_cast<const u32x4*>(kp + (size_t)key * P.ldk + ld_kc * 8);
+        zv = *reinterpret_cast<const u32x4*>(vp + (size_t)key * P.ldv + ld_kc * 8);
+      }
+      rk[i] = zk; rv[i] = zv;
+    }
+  };
+  auto store_tile = [&](int st) {
+    unsigned char* sk = smem + st * TILE_BYTES;
+    unsigned char* sv = smem + (2 + st) * TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < LD_IT; ++i) {
+      const int r = ld_row + i * (NT / 8);
+      *reinterpret_cast<u32x4*>(sk + k_off(r, ld_kc)) = rk[i];
+      *reinterpret_cast<u32x4*>(sv + v_off(r, ld_kc)) = rv[i];
+    }
+  };
+
+  f32x16 o0 = {}, o1 = {};       // O^T tiles: d 0..31 and 32..63 (rows) x query (lane)
+  float m_run = NEG_BIG, l_run = 0.f;
+  const float c = a.scale * 1.4426950408889634f;  // scale * log2(e)
+
+  const int nkb = (nk + KV_TILE - 1) / KV_TILE;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  // transposed-read lane geometry (see header): 16-lane group g reads a 4-key x 16-dim block
+  const int tr_i = lane & 15;
+  const int tr_q = tr_i >> 2, tr_p = tr_i & 3;
+  const int tr_dcol = ((lane >> 4) & 1) * 16 + tr_p * 4;   // dim offset inside a 32-dim tile
+
+  for (int kb = 0; kb < nkb; ++kb) {
+    const int cur = kb & 1;
+    const bool more = kb + 1 < nkb;
+    if (more) load_tile(kb + 1);
+    const unsigned char* sk = smem + cur * TILE_BYTES;
+    const unsigned char* sv = smem + (2 + cur) * TILE_BYTES;
+
+    // ---- S^T = K.Q^T for the two 32-key sub tiles
+    f32x16 s0 = {}, s1 = {};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(sk + k_off(lq, ks * 2 + lh));
+      const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(sk + k_off(32 + lq, ks * 2 + lh));
+      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[ks], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[ks], s1, 0, 0, 0);
+    }
+    // ---- mask keys beyond nk (only the last tile can be ragged)
+    if (kb * KV_TILE + KV_TILE > nk) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kb * KV_TILE + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (key >= nk) s0[r] = NEG_BIG;
+        if (key + 32 >= nk) s1[r] = NEG_BIG;
+      }
+    }
+    // ---- online softmax (this lane: one query, 32 of the 64 keys; partner lane^32 has the rest)
+    float mx = s0[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s0[r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s1[r]);
+    mx = pair_max(mx);
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = exp2f((m_run - m_new) * c);
+    const float mc = m_new * c;
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s0[r] = exp2f(fmaf(s0[r], c, -mc));
+      s1[r] = exp2f(fmaf(s1[r], c, -mc));
+      psum += s0[r] + s1[r];
+    }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+
+    // ---- P^T as bf16 B operands: k-step s (16 keys) of sub tile t = accumulator regs 8s..8s+7
+    bf16x8 pb[4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      pb[0][j] = (__bf16)s0[j];
+      pb[1][j] = (__bf16)s0[8 + j];
+      pb[2][j] = (__bf16)s1[j];
+      pb[3][j] = (__bf16)s1[8 + j];
+    }
+    // ---- O^T += V^T . P^T ; A operand element j of lane (d, h) = V[key0 + 8*(j>>2) + 4h + (j&3)][d]
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {          // st = 2*subtile + kstep  -> key0 = 16*st
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const int keyA = st * 16 + 4 * lh + tr_q;
+        const int col = dt * 32 + tr_dcol;     // bf16 column inside the 64-dim row
+        const int offA = v_off(keyA, col >> 3) + (col & 7) * 2;
+        const int offB = v_off(keyA + 8, col >> 3) + (col & 7) * 2;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(sv + offA));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(sv + offB));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const bf16x8 vf = __builtin_bit_cast(bf16x8, both);
+        if (dt == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[st], o0, 0, 0, 0);
+        else         o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[st], o1, 0, 0, 0);
+      }
+    }
+    if (more) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: O[q][d] = O^T / l ; lane holds d = 32*dt + (r&3) + 8*(r>>2) + 4*lh
+  const float inv = 1.0f / pair_sum(l_run);
+  if (qrow < nq) {
+    bf16_t* orow = op + (size_t)qrow * P.ldo;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      u32x2 w0 = {pack2bf(o0[4 * g] * inv, o0[4 * g + 1] * inv), pack2bf(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv)};
+      u32x2 w1 = {pack2bf(o1[4 * g] * inv, o1[4 * g + 1] * inv), pack2bf(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv)};
+      *reinterpret_cast<u32x2*>(orow + 8 * g + 4 * lh) = w0;
+      *reinterpret_cast<u32x2*>(orow + 32 + 8 * g + 4 * lh) = w1;
+    }
+  }
+}
+
+template <int NW>
+int launch_nw(const MvdAttnArgs& a, int maxq, hipStream_t s) {
+  const int qb = 32 * NW;
+  dim3 grid((maxq + qb - 1) / qb, a.heads, a.batch * a.nprob);
+  hipLaunchKernelGGL(attn_kernel<NW>, grid, dim3(64 * NW), 0, s, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { mvd_set_error("attention launch: %s", hipGetErrorString(e)); return -3; }
+  return 0;
+}
+
+}  // namespace
+
+int mvd_launch_attention(const MvdAttnArgs& a, hipStream_t s) {
+  if (a.nprob < 1 || a.nprob > 2 || a.batch <= 0 || a.heads <= 0) { mvd_set_error("attention: bad problem count/batch/heads"); return -1; }
+  int maxq = 0;
+  for (int i = 0; i < a.nprob; ++i) {
+    const MvdAttnProblem& p = a.p[i];
+    if (!p.q || !p.k || !p.v || !p.o || p.nq <= 0 || p.nk <= 0) { mvd_set_error("attention: null pointer or empty problem %d", i); return -1; }
+    if ((p.ldq % 8) || (p.ldk % 8) || (p.ldv % 8) || (p.ldo % 4) || p.ldq < a.heads * 64 || p.ldk < a.heads * 64 || p.ldv < a.heads * 64 || p.ldo < a.heads * 64) { mvd_set_error("attention: bad strides in problem %d", i); return -1; }
+    if (((uintptr_t)p.q | (uintptr_t)p.k | (uintptr_t)p.v) & 15 || ((uintptr_t)p.o & 7)) { mvd_set_error("attention: misaligned pointer in problem %d", i); return -1; }
+    if ((p.bsq % 8) || (p.bsk % 8) || (p.bsv % 8) || (p.bso % 4)) { mvd_set_error("attention: bad batch strides in problem %d", i); return -1; }
+    maxq = p.nq > maxq ? p.nq : maxq;
+  }
+  // enough workgroups to fill 256 CUs: prefer 8 waves (256 queries) per workgroup, shrink for small problems
+  const long heads_total = (long)a.heads * a.batch * a.nprob;
+  if (maxq >= 256 && heads_total * ((maxq + 255) / 256) >= 512) return launch_nw<8>(a, maxq, s);
+  if (maxq >= 128 && heads_total * ((maxq + 127) / 128) >= 512) return launch_nw<4>(a, maxq, s);
+  if (maxq >= 64) return launch_nw<2>(a, maxq, s);
+  return launch_nw<1>(a, maxq, s);
+}

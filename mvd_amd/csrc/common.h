@@ -1,0 +1,44 @@
+// Shared device/host helpers for the MVD hot-path kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;  // storage type for bf16 in global memory / LDS
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+#define MVD_DEVINL __device__ __forceinline__
+
+MVD_DEVINL float bf2f(bf16_t v) { return __builtin_bit_cast(float, (unsigned int)v << 16); }
+// plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN stays NaN)
+MVD_DEVINL bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+MVD_DEVINL unsigned int pack2bf(float lo, float hi) {
+  bf16x2 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned int, v);
+}
+MVD_DEVINL float bflo(unsigned int u) { return __builtin_bit_cast(float, u << 16); }
+MVD_DEVINL float bfhi(unsigned int u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+
+MVD_DEVINL float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+MVD_DEVINL float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+MVD_DEVINL float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// XCD-aware bijective block remap (blocks b, b+8, ... share an XCD): gives each XCD a
+// contiguous chunk of the logical tile order so neighbouring tiles hit the same L2.
+MVD_DEVINL int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+  const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + (bid >> 3);
+}

@@ -1,0 +1,771 @@
+// Host-side schedule of one MultiViewUNet.forward on one MI355X: the whole forward
+// (camera encoder -> reference-image encoder UNet -> adapter K/V -> main UNet) is issued
+// from C++ behind a single C-ABI call; Python only hands over device pointers.
+//
+// Follows /root/reference/src/models/mvd_unet.py:179-338 (orchestration),
+// image_encoder.py:97-112 (encoder pass at t=0, 16 captured maps),
+// attention.py:48-188 (adapter branch), camera_encoder.py:160-255 (embedding + FiLM) and
+// the diffusers-0.32.2 UNet2DConditionModel layer order.
+#include <math.h>
+#include <string.h>
+
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/mvd_hip.h"
+#include "kernels.h"
+
+int mvd_launch_silu_to_bf16(const float* x, int64_t n, bf16_t* y, hipStream_t s);
+
+namespace {
+
+struct Weight { const void* p; int64_t numel; int dtype; };
+
+struct Arena {
+  char* base = nullptr;
+  size_t cap = 0, off = 0, high = 0;
+  bool dry = false;
+  void* alloc(size_t bytes) {
+    off = (off + 255) & ~size_t(255);
+    void* p = dry ? (void*)(uintptr_t)(0x1000 + off) : (void*)(base + off);
+    off += bytes;
+    if (off > high) high = off;
+    return p;
+  }
+  bool overflow() const { return !dry && high > cap; }
+};
+
+struct Act {  // NHWC bf16 activation
+  bf16_t* p = nullptr;
+  int B = 0, H = 0, W = 0, C = 0;
+  int hw() const { return H * W; }
+  int rows() const { return B * H * W; }
+};
+
+struct FeatureInfo { std::string name; int level; int C; int heads; };
+
+}  // namespace
+
+struct mvd_engine {
+  mvd_config_t cfg;
+  std::unordered_map<std::string, Weight> w[2];
+  Arena tmp, act, persist;
+  void* ws_ptr = nullptr; int64_t ws_bytes = 0;
+  void* rc_ptr = nullptr; int64_t rc_bytes = 0;
+  std::vector<FeatureInfo> feats;
+  // reference cache state (valid after a forward with MVD_USE_IMAGE)
+  std::vector<bf16_t*> refkv;       // per feature: [ref_batch*hw][4C]
+  std::vector<bf16_t*> feat_keep;   // per feature: [ref_batch][hw][C] when kept
+  int rc_batch = 0, rc_h = 0, rc_w = 0; bool rc_valid = false; bool rc_keep = false;
+  float* cam_emb = nullptr; int cam_batch = 0;
+  std::vector<int> temb_off;        // per resnet offset into the fused time_emb_proj output
+  int temb_total = 0;
+};
+
+namespace {
+
+#define CHECK(x) do { int _r = (x); if (_r) return _r; } while (0)
+
+struct Ctx {
+  mvd_engine* e;
+  hipStream_t s;
+  int set;          // weight set of the current UNet pass
+  bool dry;
+  int err = 0;
+
+  const Weight* W(const std::string& name, int dtype, int64_t numel, int set_override = -1) {
+    if (dry) return nullptr;  // sizing run: weights need not be registered
+    const int st = set_override >= 0 ? set_override : set;
+    auto it = e->w[st].find(name);
+    if (it == e->w[st].end()) { mvd_set_error("missing weight slot '%s' in set %d", name.c_str(), st); err = -10; return nullptr; }
+    if (it->second.dtype != dtype || it->second.numel != numel) {
+      mvd_set_error("weight slot '%s' (set %d): expected dtype %d numel %lld, got dtype %d numel %lld", name.c_str(), st, dtype,
+                    (long long)numel, it->second.dtype, (long long)it->second.numel);
+      err = -11; return nullptr;
+    }
+    return &it->second;
+  }
+  const bf16_t* WB(const std::string& n, int64_t numel, int so = -1) { auto* w = W(n, 1, numel, so); return w ? (const bf16_t*)w->p : nullptr; }
+  const float* WF(const std::string& n, int64_t numel, int so = -1) { auto* w = W(n, 0, numel, so); return w ? (const float*)w->p : nullptr; }
+  bool has(const std::string& n, int so = -1) { const int st = so >= 0 ? so : set; return e->w[st].count(n) != 0; }
+
+  template <class T> T* talloc(size_t n) { return (T*)e->tmp.alloc(n * sizeof(T)); }
+  template <class T> T* aalloc(size_t n) { return (T*)e->act.alloc(n * sizeof(T)); }
+  Act new_act(int B, int H, int W_, int C, bool longlived) {
+    Act a; a.B = B; a.H = H; a.W = W_; a.C = C;
+    a.p = longlived ? aalloc<bf16_t>((size_t)B * H * W_ * C) : talloc<bf16_t>((size_t)B * H * W_ * C);
+    return a;
+  }
+
+  // ------------------------------------------------------------------ op wrappers
+  int gemm(MvdGemmArgs& g) { if (err) return err; if (dry) return 0; return mvd_launch_gemm(g, s); }
+
+  // dense linear: out[M][N] = alpha*(A.W^T + bias) + res
+  int linear(const bf16_t* a, const bf16_t* a2, int k1, int k2, int M, const bf16_t* w, const float* bias, int N,
+             const bf16_t* res, int ldres, void* out, int ldo, bool geglu = false, bool out_f32 = false) {
+    MvdGemmArgs g; memset(&g, 0, sizeof(g));
+    g.seg[0].p0 = a; g.seg[0].p1 = a2; g.seg[0].c0 = k1; g.seg[0].c1 = k2; g.seg[0].mode = MVD_A_DENSE; g.seg[0].ksize = k1 + k2;
+    g.nseg = 1; g.W = w; g.M = M; g.N = N; g.Ktot = k1 + k2; g.rows_per_batch = M; g.outH = 1; g.outW = M;
+    g.bias = bias; g.res = res; g.ldres = ldres; g.alpha = 1.f; g.geglu = geglu; g.out = out; g.ldo = ldo; g.out_f32 = out_f32;
+    return gemm(g);
+  }
+
+  int conv3(const Act& x, int stride, int ups, const bf16_t* w, const float* bias, const float* rowvec, int ld_rowvec,
+            const bf16_t* res, const bf16_t* sc0, const bf16_t* sc1, int scc0, int scc1, Act& out) {
+    MvdGemmArgs g; memset(&g, 0, sizeof(g));
+    g.seg[0].p0 = x.p; g.seg[0].c0 = x.C; g.seg[0].mode = MVD_A_CONV3; g.seg[0].ksize = 9 * x.C;
+    g.seg[0].inH = x.H; g.seg[0].inW = x.W; g.seg[0].stride = stride; g.seg[0].ups = ups;
+    g.nseg = 1; g.Ktot = 9 * x.C;
+    if (sc0) {
+      g.seg[1].p0 = sc0; g.seg[1].p1 = sc1; g.seg[1].c0 = scc0; g.seg[1].c1 = scc1; g.seg[1].mode = MVD_A_DENSE;
+      g.seg[1].ksize = scc0 + scc1; g.nseg = 2; g.Ktot += scc0 + scc1;
+    }
+    g.W = w; g.M = out.rows(); g.N = out.C; g.rows_per_batch = out.hw(); g.outH = out.H; g.outW = out.W;
+    g.bias = bias; g.rowvec = rowvec; g.ld_rowvec = ld_rowvec; g.res = res; g.ldres = out.C; g.alpha = 1.f;
+    g.out = out.p; g.ldo = out.C;
+    return gemm(g);
+  }
+
+  int groupnorm(const bf16_t* x0, const bf16_t* x1, int c0, int c1, int B, int hw, float eps, const float* g, const float* b,
+                int silu, bf16_t* y) {
+    if (err) return err;
+    const int groups = e->cfg.norm_num_groups;
+    float* ws = talloc<float>((size_t)B * MVD_GN_MAXCHUNK * groups * 2);
+    if (dry) return 0;
+    return mvd_launch_groupnorm(x0, x1, c0, c1, B, hw, groups, eps, g, b, silu, y, ws, s);
+  }
+  int layernorm(const bf16_t* x, int rows, int c, const float* g, const float* b, bf16_t* y) {
+    if (err) return err; if (dry) return 0;
+    return mvd_launch_layernorm(x, rows, c, 1e-5f, g, b, y, s);
+  }
+  int attention(MvdAttnArgs& a) { if (err) return err; if (dry) return 0; return mvd_launch_attention(a, s); }
+};
+
+// ---------------------------------------------------------------------- structure helpers
+struct ResnetDesc { std::string key; int cin0, cin1, cout; };
+
+std::vector<ResnetDesc> enumerate_resnets(const mvd_config_t& c) {
+  std::vector<ResnetDesc> v;
+  const int n = c.num_levels, L = c.layers_per_block;
+  int prev = c.block_out_channels[0];
+  for (int i = 0; i < n; ++i) {
+    const int co = c.block_out_channels[i];
+    for (int j = 0; j < L; ++j) v.push_back({"down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), j == 0 ? prev : co, 0, co});
+    prev = co;
+  }
+  const int cm = c.block_out_channels[n - 1];
+  v.push_back({"mid_block.resnets.0", cm, 0, cm});
+  v.push_back({"mid_block.resnets.1", cm, 0, cm});
+  int prev_out = cm;
+  for (int i = 0; i < n; ++i) {
+    const int out_c = c.block_out_channels[n - 1 - i];
+    const int in_c = c.block_out_channels[n - 1 - (i + 1 < n ? i + 1 : n - 1)];
+    for (int j = 0; j <= L; ++j) {
+      const int skip = (j == L) ? in_c : out_c;
+      const int hid = (j == 0) ? prev_out : out_c;
+      v.push_back({"up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), hid, skip, out_c});
+    }
+    prev_out = out_c;
+  }
+  return v;
+}
+
+std::vector<FeatureInfo> enumerate_features(const mvd_config_t& c) {
+  std::vector<FeatureInfo> f;
+  const int n = c.num_levels, L = c.layers_per_block;
+  for (int i = 0; i + 1 < n; ++i)
+    for (int j = 0; j < L; ++j) f.push_back({"down_block_" + std::to_string(i) + "_attn_" + std::to_string(j), i, c.block_out_channels[i], c.num_heads[i]});
+  f.push_back({"mid_block_attn_0", n - 1, c.block_out_channels[n - 1], c.num_heads[n - 1]});
+  for (int i = 1; i < n; ++i)
+    for (int j = 0; j <= L; ++j) f.push_back({"up_block_" + std::to_string(i) + "_attn_" + std::to_string(j), n - 1 - i, c.block_out_channels[n - 1 - i], c.num_heads[n - 1 - i]});
+  return f;
+}
+
+struct PassOpts {
+  bool adapter = false;       // add the cross-view attention branch (needs e->refkv)
+  bool film = false;          // apply camera FiLM hooks
+  bool capture = false;       // encoder pass: produce reference K/V (+ keep features)
+  int ref_batch = 0;          // batch of the reference features (Q4 re-chunking)
+  const std::unordered_map<std::string, std::pair<float*, float*>>* film_ss = nullptr;  // name -> (scale, shift) [B][dim]
+};
+
+// ---------------------------------------------------------------------- one UNet pass
+struct UNetPass {
+  Ctx& c;
+  const mvd_config_t& cfg;
+  PassOpts o;
+  int B, H0, W0, L;
+  const bf16_t* text;      // [B*L][xdim] bf16
+  const float* tproj;      // [B][temb_total] fp32 (all time_emb_proj outputs incl. bias)
+  int resnet_idx = 0;
+  int feat_idx = 0;
+
+  int resnet(const std::string& key, const Act& x0, const Act* x1, int cout, Act& out) {
+    const int cin0 = x0.C, cin1 = x1 ? x1->C : 0, cin = cin0 + cin1;
+    const int B_ = x0.B, hw = x0.hw();
+    const size_t mark = c.e->tmp.off;
+    Act t1 = c.new_act(B_, x0.H, x0.W, cin, false);
+    CHECK(c.groupnorm(x0.p, x1 ? x1->p : nullptr, cin0, cin1, B_, hw, cfg.norm_eps, c.WF(key + ".norm1.g", cin), c.WF(key + ".norm1.b", cin), 1, t1.p));
+    Act h1 = c.new_act(B_, x0.H, x0.W, cout, false);
+    const int toff = c.e->temb_off[resnet_idx++];
+    CHECK(c.conv3(t1, 1, 0, c.WB(key + ".conv1.w", (int64_t)cout * 9 * cin), c.WF(key + ".conv1.b", cout), tproj + toff, c.e->temb_total,
+                  nullptr, nullptr, nullptr, 0, 0, h1));
+    Act t2 = c.new_act(B_, x0.H, x0.W, cout, false);
+    CHECK(c.groupnorm(h1.p, nullptr, cout, 0, B_, hw, cfg.norm_eps, c.WF(key + ".norm2.g", cout), c.WF(key + ".norm2.b", cout), 1, t2.p));
+    if (cin != cout) {
+      CHECK(c.conv3(t2, 1, 0, c.WB(key + ".conv2.w", (int64_t)cout * (9 * cout + cin)), c.WF(key + ".conv2.b", cout), nullptr, 0, nullptr,
+                    x0.p, x1 ? x1->p : nullptr, cin0, cin1, out));
+    } else {
+      CHECK(c.conv3(t2, 1, 0, c.WB(key + ".conv2.w", (int64_t)cout * 9 * cout), c.WF(key + ".conv2.b", cout), nullptr, 0, x0.p, nullptr,
+                    nullptr, 0, 0, out));
+    }
+    c.e->tmp.off = mark;
+    return c.err;
+  }
+
+  int transformer(const std::string& key, const Act& x, int heads, Act& out) {
+    const int C = x.C, M = x.rows(), hw = x.hw(), B_ = x.B;
+    const int xd = cfg.cross_attention_dim;
+    const FeatureInfo& fi = c.e->feats[feat_idx];
+    const bool ad = o.adapter;
+    const size_t mark = c.e->tmp.off;
+    bf16_t* n0 = c.talloc<bf16_t>((size_t)M * C);
+    CHECK(c.groupnorm(x.p, nullptr, C, 0, B_, hw, 1e-6f, c.WF(key + ".norm.g", C), c.WF(key + ".norm.b", C), 0, n0));
+    bf16_t* h = c.talloc<bf16_t>((size_t)M * C);
+    CHECK(c.linear(n0, nullptr, C, 0, M, c.WB(key + ".proj_in.w", (int64_t)C * C), c.WF(key + ".proj_in.b", C), C, nullptr, 0, h, C));
+    bf16_t* ln = n0;  // reuse
+    const float scale = 0.125f;
+    bf16_t* o_self = c.talloc<bf16_t>((size_t)M * C);
+    bf16_t* o_ref = ad ? c.talloc<bf16_t>((size_t)M * C) : nullptr;
+    const bf16_t* rkv = ad ? c.e->refkv[feat_idx] : nullptr;
+    // Q4: K/V rows of the reference are re-chunked by the HIDDEN batch size
+    const int ref_nk = ad ? (int)((int64_t)o.ref_batch * hw / B_) : 0;
+    if (ad && (int64_t)ref_nk * B_ != (int64_t)o.ref_batch * hw) { mvd_set_error("adapter: ref tokens %d x %d not divisible by batch %d", o.ref_batch, hw, B_); return -12; }
+
+    // ---- attn1 (self) + adapter branch "<feature>_self"
+    {
+      const int nq = ad ? 4 * C : 3 * C;
+      bf16_t* qkv = c.talloc<bf16_t>((size_t)M * nq);
+      CHECK(c.layernorm(h, M, C, c.WF(key + ".ln1.g", C), c.WF(key + ".ln1.b", C), ln));
+      CHECK(c.linear(ln, nullptr, C, 0, M, c.WB(key + ".attn1.qkv.w", (int64_t)nq * C), nullptr, nq, nullptr, 0, qkv, nq));
+      MvdAttnArgs a; memset(&a, 0, sizeof(a));
+      a.batch = B_; a.heads = heads; a.scale = scale; a.nprob = ad ? 2 : 1;
+      a.p[0] = {qkv, qkv + C, qkv + 2 * C, o_self, nq, nq, nq, C, (int64_t)hw * nq, (int64_t)hw * nq, (int64_t)hw * nq, (int64_t)hw * C, hw, hw};
+      if (ad) a.p[1] = {qkv + 3 * C, rkv, rkv + C, o_ref, nq, 4 * C, 4 * C, C, (int64_t)hw * nq, (int64_t)ref_nk * 4 * C, (int64_t)ref_nk * 4 * C, (int64_t)hw * C, hw, ref_nk};
+      CHECK(c.attention(a));
+      const int kout = ad ? 2 * C : C;
+      CHECK(c.linear(o_self, o_ref, C, ad ? C : 0, M, c.WB(key + ".attn1.out.w", (int64_t)C * kout), c.WF(key + ".attn1.out.b", C), C, h, C, h, C));
+    }
+    // ---- attn2 (text cross) + adapter branch "<feature>_cross"
+    {
+      const int nq = ad ? 2 * C : C;
+      bf16_t* q2 = c.talloc<bf16_t>((size_t)M * nq);
+      bf16_t* kv2 = c.talloc<bf16_t>((size_t)B_ * L * 2 * C);
+      CHECK(c.layernorm(h, M, C, c.WF(key + ".ln2.g", C), c.WF(key + ".ln2.b", C), ln));
+      CHECK(c.linear(ln, nullptr, C, 0, M, c.WB(key + ".attn2.q.w", (int64_t)nq * C), nullptr, nq, nullptr, 0, q2, nq));
+      CHECK(c.linear(text, nullptr, xd, 0, B_ * L, c.WB(key + ".attn2.kv.w", (int64_t)2 * C * xd), nullptr, 2 * C, nullptr, 0, kv2, 2 * C));
+      MvdAttnArgs a; memset(&a, 0, sizeof(a));
+      a.batch = B_; a.heads = heads; a.scale = scale; a.nprob = ad ? 2 : 1;
+      a.p[0] = {q2, kv2, kv2 + C, o_self, nq, 2 * C, 2 * C, C, (int64_t)hw * nq, (int64_t)L * 2 * C, (int64_t)L * 2 * C, (int64_t)hw * C, hw, L};
+      if (ad) a.p[1] = {q2 + C, rkv + 2 * C, rkv + 3 * C, o_ref, nq, 4 * C, 4 * C, C, (int64_t)hw * nq, (int64_t)ref_nk * 4 * C, (int64_t)ref_nk * 4 * C, (int64_t)hw * C, hw, ref_nk};
+      CHECK(c.attention(a));
+      const int kout = ad ? 2 * C : C;
+      CHECK(c.linear(o_self, o_ref, C, ad ? C : 0, M, c.WB(key + ".attn2.out.w", (int64_t)C * kout), c.WF(key + ".attn2.out.b", C), C, h, C, h, C));
+    }
+    // ---- GEGLU feed-forward
+    {
+      bf16_t* ff = c.talloc<bf16_t>((size_t)M * 4 * C);
+      CHECK(c.layernorm(h, M, C, c.WF(key + ".ln3.g", C), c.WF(key + ".ln3.b", C), ln));
+      CHECK(c.linear(ln, nullptr, C, 0, M, c.WB(key + ".ff1.w", (int64_t)8 * C * C), c.WF(key + ".ff1.b", 8 * C), 8 * C, nullptr, 0, ff, 4 * C, true));
+      CHECK(c.linear(ff, nullptr, 4 * C, 0, M, c.WB(key + ".ff2.w", (int64_t)C * 4 * C), c.WF(key + ".ff2.b", C), C, h, C, h, C));
+    }
+    CHECK(c.linear(h, nullptr, C, 0, M, c.WB(key + ".proj_out.w", (int64_t)C * C), c.WF(key + ".proj_out.b", C), C, x.p, C, out.p, C));
+    c.e->tmp.off = mark;
+
+    if (o.capture) {  // encoder pass: reference normalisation (Q2) + adapter K/V for both processors of this feature
+      const size_t mk = c.e->tmp.off;
+      bf16_t* rn = c.talloc<bf16_t>((size_t)M * C);
+      if (!c.dry && !c.err) CHECK(mvd_launch_refnorm(out.p, B_, hw, C, rn, c.s));
+      CHECK(c.linear(rn, nullptr, C, 0, M, c.WB(key + ".ref_kv.w", (int64_t)4 * C * C, 0), nullptr, 4 * C, nullptr, 0, c.e->refkv[feat_idx], 4 * C));
+      if (c.e->rc_keep && !c.dry && !c.err)
+        CHECK((int)hipMemcpyAsync(c.e->feat_keep[feat_idx], out.p, (size_t)M * C * sizeof(bf16_t), hipMemcpyDeviceToDevice, c.s));
+      c.e->tmp.off = mk;
+    }
+    (void)fi;
+    ++feat_idx;
+    return c.err;
+  }
+
+  int film(const std::string& name, const Act& x, Act& out) {
+    auto it = o.film_ss->find(name);
+    if (it == o.film_ss->end()) { out = x; return 0; }   // unknown modulator ("mid_0") -> identity (Q3)
+    if (c.dry || c.err) return c.err;
+    return mvd_launch_film(x.p, x.B, x.hw(), x.C, it->second.first, it->second.second, x.C, out.p, c.s);
+  }
+
+  int run(const Act& x_in, float* out_nchw) {
+    const int n = cfg.num_levels, Lb = cfg.layers_per_block;
+    const int C0 = cfg.block_out_channels[0];
+    std::vector<Act> skips;
+    Act h = c.new_act(B, H0, W0, C0, true);
+    if (!c.dry && !c.err) CHECK(mvd_launch_conv_in(x_in.p, B, H0, W0, cfg.in_channels, c.WF("conv_in.w", (int64_t)C0 * 9 * cfg.in_channels), c.WF("conv_in.b", C0), C0, h.p, c.s));
+    else { c.WF("conv_in.w", (int64_t)C0 * 9 * cfg.in_channels); c.WF("conv_in.b", C0); }
+    skips.push_back(h);
+    for (int i = 0; i < n; ++i) {
+      const int co = cfg.block_out_channels[i];
+      const std::string bk = "down_blocks." + std::to_string(i);
+      for (int j = 0; j < Lb; ++j) {
+        Act r = c.new_act(B, h.H, h.W, co, true);
+        CHECK(resnet(bk + ".resnets." + std::to_string(j), h, nullptr, co, r));
+        h = r;
+        if (i + 1 < n) {
+          Act t = c.new_act(B, h.H, h.W, co, true);
+          CHECK(transformer(bk + ".attentions." + std::to_string(j), h, cfg.num_heads[i], t));
+          h = t;
+        }
+        skips.push_back(h);
+      }
+      if (i + 1 < n) {
+        Act d = c.new_act(B, (h.H + 1) / 2, (h.W + 1) / 2, co, true);
+        CHECK(c.conv3(h, 2, 0, c.WB(bk + ".down.w", (int64_t)co * 9 * co), c.WF(bk + ".down.b", co), nullptr, 0, nullptr, nullptr, nullptr, 0, 0, d));
+        h = d;
+        skips.push_back(h);
+      }
+      if (o.film) {  // hook modulates the block's returned hidden_states only; skips stay unmodulated (Q6)
+        Act m = c.new_act(B, h.H, h.W, h.C, true);
+        Act res = m;
+        CHECK(film("down_" + std::to_string(i), h, res));
+        h = res;
+      }
+    }
+    {
+      const int cm = cfg.block_out_channels[n - 1];
+      Act r = c.new_act(B, h.H, h.W, cm, true);
+      CHECK(resnet("mid_block.resnets.0", h, nullptr, cm, r));
+      Act t = c.new_act(B, h.H, h.W, cm, true);
+      CHECK(transformer("mid_block.attentions.0", r, cfg.num_heads[n - 1], t));
+      Act r2 = c.new_act(B, h.H, h.W, cm, true);
+      CHECK(resnet("mid_block.resnets.1", t, nullptr, cm, r2));
+      h = r2;
+      if (o.film) { Act res = h; CHECK(film("mid_0", h, res)); h = res; }
+    }
+    for (int i = 0; i < n; ++i) {
+      const int co = cfg.block_out_channels[n - 1 - i];
+      const std::string bk = "up_blocks." + std::to_string(i);
+      for (int j = 0; j <= Lb; ++j) {
+        Act skip = skips.back(); skips.pop_back();
+        if (skip.H != h.H || skip.W != h.W) { mvd_set_error("up block %d: skip %dx%d vs hidden %dx%d (odd latent size unsupported)", i, skip.H, skip.W, h.H, h.W); return -13; }
+        Act r = c.new_act(B, h.H, h.W, co, true);
+        CHECK(resnet(bk + ".resnets." + std::to_string(j), h, &skip, co, r));
+        h = r;
+        if (i > 0) {
+          Act t = c.new_act(B, h.H, h.W, co, true);
+          CHECK(transformer(bk + ".attentions." + std::to_string(j), h, cfg.num_heads[n - 1 - i], t));
+          h = t;
+        }
+      }
+      if (i + 1 < n) {
+        Act u = c.new_act(B, h.H * 2, h.W * 2, co, true);
+        CHECK(c.conv3(h, 1, 1, c.WB(bk + ".up.w", (int64_t)co * 9 * co), c.WF(bk + ".up.b", co), nullptr, 0, nullptr, nullptr, nullptr, 0, 0, u));
+        h = u;
+      }
+      if (o.film) { Act res = h; CHECK(film("up_" + std::to_string(i), h, res)); h = res; }
+    }
+    if (out_nchw) {
+      Act t = c.new_act(B, h.H, h.W, C0, false);
+      CHECK(c.groupnorm(h.p, nullptr, C0, 0, B, h.hw(), cfg.norm_eps, c.WF("conv_norm_out.g", C0), c.WF("conv_norm_out.b", C0), 1, t.p));
+      const bf16_t* wo = c.WB("conv_out.w", (int64_t)cfg.out_channels * 9 * C0);
+      const float* bo = c.WF("conv_out.b", cfg.out_channels);
+      if (!c.dry && !c.err) CHECK(mvd_launch_conv_out(t.p, B, h.H, h.W, C0, wo, bo, cfg.out_channels, out_nchw, c.s));
+    }
+    return c.err;
+  }
+};
+
+// time embedding -> fused time_emb_proj for every resnet: returns [B][temb_total] fp32
+int time_path(Ctx& c, const float* timesteps, int B, const float** tproj_out) {
+  const mvd_config_t& cfg = c.e->cfg;
+  const int C0 = cfg.block_out_channels[0], TD = 4 * C0;
+  float* sinus = c.talloc<float>((size_t)B * C0);
+  float* t1 = c.talloc<float>((size_t)B * TD);
+  float* emb = c.talloc<float>((size_t)B * TD);
+  bf16_t* act = c.talloc<bf16_t>((size_t)B * TD);
+  float* tproj = c.aalloc<float>((size_t)B * c.e->temb_total);
+  const bf16_t* w1 = c.WB("time.l1.w", (int64_t)TD * C0);
+  const float* b1 = c.WF("time.l1.b", TD);
+  const bf16_t* w2 = c.WB("time.l2.w", (int64_t)TD * TD);
+  const float* b2 = c.WF("time.l2.b", TD);
+  const bf16_t* wp = c.WB("temb_proj.w", (int64_t)c.e->temb_total * TD);
+  const float* bp = c.WF("temb_proj.b", c.e->temb_total);
+  *tproj_out = tproj;
+  if (c.err) return c.err;
+  if (c.dry) return 0;
+  CHECK(mvd_launch_timestep_embedding(timesteps, B, C0, sinus, c.s));
+  CHECK(mvd_launch_skinny_linear(sinus, C0, B, C0, w1, 1, b1, TD, 0, t1, TD, c.s));
+  CHECK(mvd_launch_skinny_linear(t1, TD, B, TD, w2, 1, b2, TD, 1, emb, TD, c.s));
+  // SiLU(emb) -> bf16 operand of the fused time_emb_proj GEMM (resnet: time_emb_proj(nonlinearity(temb)))
+  CHECK(mvd_launch_silu_to_bf16(emb, (int64_t)B * TD, act, c.s));
+  CHECK(c.linear(act, nullptr, TD, 0, B, wp, bp, c.e->temb_total, nullptr, 0, tproj, c.e->temb_total, false, true));
+  return 0;
+}
+
+// camera encoder (fp32, Q9) + FiLM parameters of every modulator
+int camera_path(Ctx& c, const mvd_forward_args_t& a, std::unordered_map<std::string, std::pair<float*, float*>>& ss) {
+  const mvd_config_t& cfg = c.e->cfg;
+  const int B = a.batch, D = cfg.cam_output_dim, Hd = cfg.cam_hidden_dim;
+  const int nfreq = (D / 2) / 3, encd = 6 * nfreq;
+  const bool simple = cfg.simple_cam_encoder != 0;
+  float* rflat = c.talloc<float>((size_t)B * 9);
+  float* enc = c.talloc<float>((size_t)B * encd);
+  float* encp = c.talloc<float>((size_t)B * D);
+  float* cat = c.talloc<float>((size_t)B * 2 * D);
+  float* bufa = c.talloc<float>((size_t)B * (D > Hd ? D : Hd));
+  float* bufb = c.talloc<float>((size_t)B * (D > Hd ? D : Hd));
+  float* emb = c.aalloc<float>((size_t)B * D);
+  c.e->cam_emb = emb; c.e->cam_batch = B;
+  auto lin = [&](const std::string& k, const float* x, int ldx, int kin, int nout, float* y, int ldy) -> int {
+    const float* w = c.WF("cam." + k + ".weight", (int64_t)nout * kin, 0);
+    const float* b = c.WF("cam." + k + ".bias", nout, 0);
+    if (c.err) return c.err; if (c.dry) return 0;
+    return mvd_launch_skinny_linear(x, ldx, B, kin, w, 0, b, nout, 0, y, ldy, c.s);
+  };
+  auto lnorm = [&](const std::string& k, const float* x, int n, int silu, float* y) -> int {
+    const float* g = c.WF("cam." + k + ".weight", n, 0);
+    const float* b = c.WF("cam." + k + ".bias", n, 0);
+    if (c.err) return c.err; if (c.dry) return 0;
+    return mvd_launch_layernorm_f32(x, B, n, 1e-5f, g, b, silu, y, c.s);
+  };
+  if (!c.dry && !c.err) {
+    CHECK(mvd_launch_camera_features(a.source_camera, a.target_camera, B, a.cam_rows, nfreq, 10.0f, rflat, enc, c.s));
+    // Q1: projection by the per-call random matrix (no bias)
+    CHECK(mvd_launch_skinny_linear(enc, encd, B, encd, a.fourier_proj, 0, nullptr, D, 0, encp, D, c.s));
+  }
+  // rotation / translation encoders -> cat[:, :D] and cat[:, D:]
+  const char* encs[2] = {"rotation_encoder", "translation_encoder"};
+  for (int t = 0; t < 2; ++t) {
+    const std::string p = encs[t];
+    const float* x = t == 0 ? rflat : encp;
+    const int kin = t == 0 ? 9 : D;
+    CHECK(lin(p + ".0", x, kin, kin, Hd, bufa, Hd));
+    CHECK(lnorm(p + ".1", bufa, Hd, 1, bufb));
+    if (simple) {
+      CHECK(lin(p + ".3", bufb, Hd, Hd, D, cat + t * D, 2 * D));
+    } else {
+      CHECK(lin(p + ".3", bufb, Hd, Hd, Hd, bufa, Hd));
+      CHECK(lnorm(p + ".4", bufa, Hd, 1, bufb));
+      CHECK(lin(p + ".6", bufb, Hd, Hd, D, cat + t * D, 2 * D));
+    }
+  }
+  CHECK(lin("final_projection.0", cat, 2 * D, 2 * D, D, bufa, D));
+  CHECK(lnorm("final_projection.1", bufa, D, 1, bufb));
+  CHECK(lin("final_projection.3", bufb, D, D, D, bufa, D));
+  CHECK(lnorm("final_projection.4", bufa, D, 0, bufb));
+  CHECK(lnorm("output_norm", bufb, D, 0, emb));
+  // modulators: name -> dim (mvd_unet.py:63-80); "mid" exists but is never addressed (hook asks for "mid_0", Q3)
+  std::vector<std::pair<std::string, int>> mods;
+  for (int i = 0; i < cfg.num_levels; ++i) mods.push_back({"down_" + std::to_string(i), cfg.block_out_channels[i]});
+  for (int i = 0; i < cfg.num_levels; ++i) mods.push_back({"up_" + std::to_string(i), cfg.block_out_channels[cfg.num_levels - 1 - i]});
+  mods.push_back({"output", cfg.in_channels});
+  float* mh = c.talloc<float>((size_t)B * (D / 2));
+  float* mh2 = c.talloc<float>((size_t)B * (D / 2));
+  for (auto& m : mods) {
+    const int dim = m.second;
+    float* raw = c.talloc<float>((size_t)B * 2 * dim);
+    float* sc = c.aalloc<float>((size_t)B * dim);
+    float* sh = c.aalloc<float>((size_t)B * dim);
+    CHECK(lin("modulators." + m.first + ".0", emb, D, D, D / 2, mh, D / 2));
+    CHECK(lnorm("modulators." + m.first + ".1", mh, D / 2, 1, mh2));
+    CHECK(lin("modulators." + m.first + ".3", mh2, D / 2, D / 2, 2 * dim, raw, 2 * dim));
+    if (!c.dry && !c.err) CHECK(mvd_launch_film_params(raw, B, dim, cfg.cam_modulation_strength, sc, sh, c.s));
+    ss[m.first] = {sc, sh};
+  }
+  return c.err;
+}
+
+int forward_impl(mvd_engine* e, const mvd_forward_args_t& a, hipStream_t s, bool dry) {
+  const mvd_config_t& cfg = e->cfg;
+  if (a.batch <= 0 || a.height <= 0 || a.width <= 0 || a.text_len <= 0) { mvd_set_error("forward: bad shape"); return -1; }
+  const int div = 1 << (cfg.num_levels - 1);
+  if (a.height % div || a.width % div) { mvd_set_error("forward: latent %dx%d must be divisible by %d", a.height, a.width, div); return -1; }
+  const bool use_cam = a.flags & MVD_USE_CAMERA, use_img = a.flags & MVD_USE_IMAGE, reuse = a.flags & MVD_REUSE_REF;
+  if (!dry) {
+    if (!a.sample || !a.timesteps || !a.text || !a.out) { mvd_set_error("forward: null sample/timesteps/text/out"); return -1; }
+    if (use_cam && (!a.source_camera || !a.target_camera || !a.fourier_proj || (a.cam_rows != 3 && a.cam_rows != 4))) { mvd_set_error("forward: camera inputs missing"); return -1; }
+    if (use_img && !reuse && (!a.source_latents || !a.encoder_text || a.ref_batch <= 0)) { mvd_set_error("forward: image-conditioning inputs missing"); return -1; }
+    if (!e->ws_ptr) { mvd_set_error("forward: workspace not bound"); return -1; }
+  }
+  if (use_img && a.ref_batch <= 0) { mvd_set_error("forward: ref_batch must be > 0 with MVD_USE_IMAGE"); return -1; }
+
+  e->tmp.dry = e->act.dry = dry;
+  e->tmp.off = e->tmp.high = 0;
+  e->act.off = e->act.high = 0;
+  Ctx c{e, s, 0, dry};
+  const int B = a.batch, H = a.height, Wd = a.width, L = a.text_len, xd = cfg.cross_attention_dim;
+
+  // ---- persistent reference cache layout
+  if (use_img) {
+    const bool keep = a.flags & MVD_KEEP_FEATURES;
+    if (reuse) {
+      if (!e->rc_valid || e->rc_batch != a.ref_batch || e->rc_h != H || e->rc_w != Wd) { mvd_set_error("forward: MVD_REUSE_REF without a matching cached reference"); return -1; }
+    } else {
+      e->persist.dry = dry; e->persist.off = e->persist.high = 0;
+      e->refkv.assign(e->feats.size(), nullptr);
+      e->feat_keep.assign(e->feats.size(), nullptr);
+      for (size_t i = 0; i < e->feats.size(); ++i) {
+        const int lv = e->feats[i].level;
+        const size_t hw = (size_t)(H >> lv) * (Wd >> lv);
+        e->refkv[i] = (bf16_t*)e->persist.alloc((size_t)a.ref_batch * hw * 4 * e->feats[i].C * sizeof(bf16_t));
+        if (keep) e->feat_keep[i] = (bf16_t*)e->persist.alloc((size_t)a.ref_batch * hw * e->feats[i].C * sizeof(bf16_t));
+      }
+      if (e->persist.overflow()) { mvd_set_error("forward: reference cache too small (%zu > %zu bytes)", e->persist.high, e->persist.cap); return -4; }
+      e->rc_keep = keep; e->rc_batch = a.ref_batch; e->rc_h = H; e->rc_w = Wd;
+      if (!dry) e->rc_valid = false;
+    }
+  }
+
+  // ---- camera path (fp32) -> embedding + FiLM scale/shift per modulator
+  std::unordered_map<std::string, std::pair<float*, float*>> film_ss;
+  if (use_cam) CHECK(camera_path(c, a, film_ss));
+
+  // ---- reference image encoder pass (frozen UNet at t = 0, plain attention) -> adapter K/V
+  if (use_img && !reuse) {
+    const size_t tm = e->tmp.off, am = e->act.off;
+    c.set = 1;
+    const int Br = a.ref_batch;
+    float* tz = c.talloc<float>(Br);
+    if (!dry) CHECK((int)hipMemsetAsync(tz, 0, Br * sizeof(float), s));
+    const float* tproj = nullptr;
+    CHECK(time_path(c, tz, Br, &tproj));
+    bf16_t* tx = c.aalloc<bf16_t>((size_t)Br * L * xd);
+    Act xin = c.new_act(Br, H, Wd, cfg.in_channels, true);
+    if (!dry && !c.err) {
+      CHECK(mvd_launch_f32_to_bf16(a.encoder_text, (int64_t)Br * L * xd, tx, s));
+      CHECK(mvd_launch_nchw_to_nhwc(a.source_latents, Br, cfg.in_channels, H * Wd, nullptr, nullptr, 0, xin.p, s));
+    }
+    PassOpts po; po.capture = true; po.ref_batch = Br;
+    UNetPass pass{c, cfg, po, Br, H, Wd, L, tx, tproj};
+    CHECK(pass.run(xin, nullptr));
+    if (!dry) e->rc_valid = true;
+    e->tmp.off = tm; e->act.off = am;   // encoder activations are dead; reuse their memory
+  }
+
+  // ---- main pass
+  c.set = 0;
+  const float* tproj = nullptr;
+  CHECK(time_path(c, a.timesteps, B, &tproj));
+  bf16_t* tx = c.aalloc<bf16_t>((size_t)B * L * xd);
+  Act xin = c.new_act(B, H, Wd, cfg.in_channels, true);
+  if (!dry && !c.err) {
+    CHECK(mvd_launch_f32_to_bf16(a.text, (int64_t)B * L * xd, tx, s));
+    const float* sc = nullptr; const float* sh = nullptr;
+    if (use_cam) { sc = film_ss["output"].first; sh = film_ss["output"].second; }   // mvd_unet.py:256-258
+    CHECK(mvd_launch_nchw_to_nhwc(a.sample, B, cfg.in_channels, H * Wd, sc, sh, cfg.in_channels, xin.p, s));
+  }
+  PassOpts po; po.adapter = use_img; po.film = use_cam; po.ref_batch = a.ref_batch; po.film_ss = &film_ss;
+  UNetPass pass{c, cfg, po, B, H, Wd, L, tx, tproj};
+  CHECK(pass.run(xin, a.out));
+  if (c.err) return c.err;
+  if (!dry && (e->tmp.high + e->act.high > (size_t)e->ws_bytes)) { mvd_set_error("forward: workspace too small"); return -4; }
+  return 0;
+}
+
+}  // namespace
+
+// silu -> bf16 helper kernel (time embedding activation)
+__global__ void silu_to_bf16_kernel(const float* __restrict__ x, long n, bf16_t* __restrict__ y) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = f2bf(silu_f(x[i]));
+}
+int mvd_launch_silu_to_bf16(const float* x, int64_t n, bf16_t* y, hipStream_t s) {
+  int grid = (int)((n + 255) / 256); if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(silu_to_bf16_kernel, dim3(grid), dim3(256), 0, s, x, (long)n, y);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { mvd_set_error("silu_to_bf16 launch: %s", hipGetErrorString(e)); return -3; }
+  return 0;
+}
+
+// =========================================================================== C ABI
+extern "C" {
+
+int mvd_engine_create(const mvd_config_t* cfg, mvd_engine_t** out) {
+  if (!cfg || !out) { mvd_set_error("engine_create: null argument"); return -1; }
+  if (cfg->num_levels < 2 || cfg->num_levels > MVD_MAX_LEVELS || cfg->layers_per_block < 1) { mvd_set_error("engine_create: unsupported topology"); return -1; }
+  for (int i = 0; i < cfg->num_levels; ++i) {
+    const int c = cfg->block_out_channels[i];
+    if (c % 64 || c % cfg->norm_num_groups || cfg->num_heads[i] * 64 != c) { mvd_set_error("engine_create: level %d: channels %d must be a multiple of 64/groups with head_dim 64 (heads %d)", i, c, cfg->num_heads[i]); return -1; }
+  }
+  if (cfg->cross_attention_dim % 64) { mvd_set_error("engine_create: cross_attention_dim must be a multiple of 64"); return -1; }
+  if (cfg->in_channels > 16 || cfg->out_channels > 8) { mvd_set_error("engine_create: in/out channels too large"); return -1; }
+  mvd_engine* e = new mvd_engine();
+  e->cfg = *cfg;
+  e->feats = enumerate_features(*cfg);
+  int off = 0;
+  for (auto& r : enumerate_resnets(*cfg)) { e->temb_off.push_back(off); off += r.cout; }
+  e->temb_total = off;
+  *out = e;
+  return 0;
+}
+
+int mvd_engine_destroy(mvd_engine_t* e) { delete e; return 0; }
+
+int mvd_engine_set_weight(mvd_engine_t* e, int set, const char* slot, const void* ptr, int64_t numel, int dtype) {
+  if (!e || set < 0 || set > 1 || !slot || !ptr || numel <= 0 || dtype < 0 || dtype > 1) { mvd_set_error("set_weight: bad argument"); return -1; }
+  if ((uintptr_t)ptr & 15) { mvd_set_error("set_weight: '%s' must be 16-byte aligned", slot); return -1; }
+  e->w[set][slot] = Weight{ptr, numel, dtype};
+  return 0;
+}
+int mvd_engine_clear_weights(mvd_engine_t* e, int set) {
+  if (!e || set < 0 || set > 1) { mvd_set_error("clear_weights: bad argument"); return -1; }
+  e->w[set].clear();
+  return 0;
+}
+
+static void fill_dry_args(mvd_forward_args_t& a, int batch, int h, int w, int L, int ref_batch) {
+  memset(&a, 0, sizeof(a));
+  a.batch = batch; a.height = h; a.width = w; a.text_len = L; a.ref_batch = ref_batch; a.cam_rows = 4;
+  a.flags = MVD_USE_CAMERA | (ref_batch > 0 ? MVD_USE_IMAGE : 0);
+}
+
+int64_t mvd_engine_workspace_bytes(mvd_engine_t* e, int batch, int height, int width, int text_len, int ref_batch) {
+  if (!e) { mvd_set_error("workspace_bytes: null engine"); return -1; }
+  mvd_forward_args_t a; fill_dry_args(a, batch, height, width, text_len, ref_batch);
+  const bool valid = e->rc_valid;
+  std::vector<bf16_t*> kv = e->refkv, fk = e->feat_keep;
+  const bool keep = e->rc_keep; const int rb = e->rc_batch, rh = e->rc_h, rw = e->rc_w;
+  int r = forward_impl(e, a, nullptr, true);
+  e->rc_valid = valid; e->refkv = kv; e->feat_keep = fk; e->rc_keep = keep; e->rc_batch = rb; e->rc_h = rh; e->rc_w = rw;
+  if (r) return r;
+  // act and tmp arenas share one buffer: [act | tmp]
+  return (int64_t)(((e->act.high + 255) & ~size_t(255)) + e->tmp.high + 4096);
+}
+
+int64_t mvd_engine_refcache_bytes(mvd_engine_t* e, int ref_batch, int height, int width, int keep_features) {
+  if (!e || ref_batch <= 0) { mvd_set_error("refcache_bytes: bad argument"); return -1; }
+  size_t total = 0;
+  for (auto& f : e->feats) {
+    const size_t hw = (size_t)(height >> f.level) * (width >> f.level);
+    total += (((size_t)ref_batch * hw * 4 * f.C * 2) + 255) & ~size_t(255);
+    if (keep_features) total += (((size_t)ref_batch * hw * f.C * 2) + 255) & ~size_t(255);
+  }
+  return (int64_t)total + 4096;
+}
+
+int mvd_engine_bind_workspace(mvd_engine_t* e, void* ws, int64_t ws_bytes, void* refcache, int64_t refcache_bytes) {
+  if (!e || !ws || ws_bytes <= 0) { mvd_set_error("bind_workspace: bad argument"); return -1; }
+  if (((uintptr_t)ws & 255) || (refcache && ((uintptr_t)refcache & 255))) { mvd_set_error("bind_workspace: buffers must be 256-byte aligned"); return -1; }
+  e->ws_ptr = ws; e->ws_bytes = ws_bytes;
+  e->rc_ptr = refcache; e->rc_bytes = refcache_bytes;
+  e->persist.base = (char*)refcache; e->persist.cap = (size_t)(refcache ? refcache_bytes : 0);
+  e->rc_valid = false;
+  return 0;
+}
+
+int mvd_unet_forward(mvd_engine_t* e, const mvd_forward_args_t* args, void* stream) {
+  if (!e || !args) { mvd_set_error("forward: null argument"); return -1; }
+  // size the two arenas for this shape with a dry run (pure host arithmetic), then run for real
+  const bool valid = e->rc_valid;
+  std::vector<bf16_t*> kv = e->refkv, fk = e->feat_keep;
+  const bool keep = e->rc_keep; const int rb = e->rc_batch, rh = e->rc_h, rw = e->rc_w;
+  int r = forward_impl(e, *args, nullptr, true);
+  e->rc_valid = valid; e->refkv = kv; e->feat_keep = fk; e->rc_keep = keep; e->rc_batch = rb; e->rc_h = rh; e->rc_w = rw;
+  if (r) return r;
+  const size_t act_bytes = (e->act.high + 255) & ~size_t(255);
+  if (!e->ws_ptr || act_bytes + e->tmp.high > (size_t)e->ws_bytes) {
+    mvd_set_error("forward: workspace too small: need %zu bytes, bound %lld", act_bytes + e->tmp.high, (long long)e->ws_bytes);
+    return -4;
+  }
+  e->act.base = (char*)e->ws_ptr; e->act.cap = act_bytes;
+  e->tmp.base = (char*)e->ws_ptr + act_bytes; e->tmp.cap = (size_t)e->ws_bytes - act_bytes;
+  return forward_impl(e, *args, (hipStream_t)stream, false);
+}
+
+int mvd_engine_num_features(mvd_engine_t* e) { return e ? (int)e->feats.size() : -1; }
+int mvd_engine_feature_shape(mvd_engine_t* e, int idx, int* channels, int* height, int* width) {
+  if (!e || idx < 0 || idx >= (int)e->feats.size() || !e->rc_h) { mvd_set_error("feature_shape: bad index or no reference pass yet"); return -1; }
+  *channels = e->feats[idx].C; *height = e->rc_h >> e->feats[idx].level; *width = e->rc_w >> e->feats[idx].level;
+  return 0;
+}
+int mvd_engine_get_feature(mvd_engine_t* e, int idx, float* out_nchw, void* stream) {
+  if (!e || idx < 0 || idx >= (int)e->feats.size() || !out_nchw) { mvd_set_error("get_feature: bad argument"); return -1; }
+  if (!e->rc_valid || !e->rc_keep || !e->feat_keep[idx]) { mvd_set_error("get_feature: no kept features (run forward with MVD_KEEP_FEATURES)"); return -1; }
+  const int lv = e->feats[idx].level;
+  return mvd_launch_nhwc_to_nchw_f32(e->feat_keep[idx], e->rc_batch, (e->rc_h >> lv) * (e->rc_w >> lv), e->feats[idx].C, out_nchw, (hipStream_t)stream);
+}
+int mvd_engine_get_camera_embedding(mvd_engine_t* e, float* out, void* stream) {
+  if (!e || !out || !e->cam_emb) { mvd_set_error("get_camera_embedding: no camera pass yet"); return -1; }
+  return (int)hipMemcpyAsync(out, e->cam_emb, (size_t)e->cam_batch * e->cfg.cam_output_dim * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------ operator-level entry points
+int mvd_op_linear(const void* a, const void* a2, int k1, int k2, const void* w, const float* bias, const float* rowvec,
+                  int ld_rowvec, int rows_per_batch, const void* res, float alpha, int geglu, void* out, int out_f32, int m,
+                  int n, int force_cfg, void* stream) {
+  MvdGemmArgs g; memset(&g, 0, sizeof(g));
+  g.seg[0].p0 = (const bf16_t*)a; g.seg[0].p1 = (const bf16_t*)a2; g.seg[0].c0 = k1; g.seg[0].c1 = k2;
+  g.seg[0].mode = MVD_A_DENSE; g.seg[0].ksize = k1 + k2; g.nseg = 1;
+  g.W = (const bf16_t*)w; g.M = m; g.N = n; g.Ktot = k1 + k2;
+  g.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : m; g.outH = 1; g.outW = g.rows_per_batch;
+  g.bias = bias; g.rowvec = rowvec; g.ld_rowvec = ld_rowvec; g.res = (const bf16_t*)res;
+  const int on = geglu ? n / 2 : n;
+  g.ldres = on; g.alpha = alpha; g.geglu = geglu; g.out = out; g.ldo = on; g.out_f32 = out_f32;
+  return mvd_launch_gemm(g, (hipStream_t)stream, force_cfg);
+}
+
+int mvd_op_conv3x3(const void* x, int batch, int in_h, int in_w, int cin, int stride, int upsample, const void* w,
+                   const float* bias, const float* rowvec, int ld_rowvec, const void* res, const void* sc, const void* sc2,
+                   int sc_c1, int sc_c2, void* out, int cout, int force_cfg, void* stream) {
+  MvdGemmArgs g; memset(&g, 0, sizeof(g));
+  const int oh = upsample ? in_h * 2 : (stride == 2 ? (in_h + 1) / 2 : in_h);
+  const int ow = upsample ? in_w * 2 : (stride == 2 ? (in_w + 1) / 2 : in_w);
+  g.seg[0].p0 = (const bf16_t*)x; g.seg[0].c0 = cin; g.seg[0].mode = MVD_A_CONV3; g.seg[0].ksize = 9 * cin;
+  g.seg[0].inH = in_h; g.seg[0].inW = in_w; g.seg[0].stride = stride; g.seg[0].ups = upsample;
+  g.nseg = 1; g.Ktot = 9 * cin;
+  if (sc) {
+    g.seg[1].p0 = (const bf16_t*)sc; g.seg[1].p1 = (const bf16_t*)sc2; g.seg[1].c0 = sc_c1; g.seg[1].c1 = sc_c2;
+    g.seg[1].mode = MVD_A_DENSE; g.seg[1].ksize = sc_c1 + sc_c2; g.nseg = 2; g.Ktot += sc_c1 + sc_c2;
+  }
+  g.W = (const bf16_t*)w; g.M = batch * oh * ow; g.N = cout; g.rows_per_batch = oh * ow; g.outH = oh; g.outW = ow;
+  g.bias = bias; g.rowvec = rowvec; g.ld_rowvec = ld_rowvec; g.res = (const bf16_t*)res; g.ldres = cout; g.alpha = 1.f;
+  g.out = out; g.ldo = cout;
+  return mvd_launch_gemm(g, (hipStream_t)stream, force_cfg);
+}
+
+int mvd_op_attention(const void* q, const void* k, const void* v, void* o, int batch, int heads, int nq, int nk, int ldq,
+                     int ldk, int ldv, int ldo, float scale, void* stream) {
+  MvdAttnArgs a; memset(&a, 0, sizeof(a));
+  a.nprob = 1; a.batch = batch; a.heads = heads; a.scale = scale;
+  a.p[0] = {(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, ldq, ldk, ldv, ldo,
+            (int64_t)nq * ldq, (int64_t)nk * ldk, (int64_t)nk * ldv, (int64_t)nq * ldo, nq, nk};
+  return mvd_launch_attention(a, (hipStream_t)stream);
+}
+
+int mvd_op_groupnorm(const void* x0, const void* x1, int c0, int c1, int batch, int hw, int groups, float eps,
+                     const float* gamma, const float* beta, int silu, void* y, float* ws, void* stream) {
+  return mvd_launch_groupnorm((const bf16_t*)x0, (const bf16_t*)x1, c0, c1, batch, hw, groups, eps, gamma, beta, silu, (bf16_t*)y, ws, (hipStream_t)stream);
+}
+int mvd_op_layernorm(const void* x, int rows, int c, float eps, const float* gamma, const float* beta, void* y, void* stream) {
+  return mvd_launch_layernorm((const bf16_t*)x, rows, c, eps, gamma, beta, (bf16_t*)y, (hipStream_t)stream);
+}
+int mvd_op_refnorm(const void* x, int batch, int hw, int c, void* y, void* stream) {
+  return mvd_launch_refnorm((const bf16_t*)x, batch, hw, c, (bf16_t*)y, (hipStream_t)stream);
+}
+int mvd_op_film(const void* x, int batch, int hw, int c, const float* scale, const float* shift, void* y, void* stream) {
+  return mvd_launch_film((const bf16_t*)x, batch, hw, c, scale, shift, c, (bf16_t*)y, (hipStream_t)stream);
+}
+int mvd_op_conv_in(const void* x, int batch, int h, int w, int cin, const float* wt, const float* bias, int cout, void* y, void* stream) {
+  return mvd_launch_conv_in((const bf16_t*)x, batch, h, w, cin, wt, bias, cout, (bf16_t*)y, (hipStream_t)stream);
+}
+int mvd_op_conv_out(const void* x, int batch, int h, int w, int c, const void* wt, const float* bias, int cout, float* y, void* stream) {
+  return mvd_launch_conv_out((const bf16_t*)x, batch, h, w, c, (const bf16_t*)wt, bias, cout, y, (hipStream_t)stream);
+}
+int mvd_op_nchw_to_nhwc(const float* x, int batch, int c, int hw, const float* scale, const float* shift, void* y, void* stream) {
+  return mvd_launch_nchw_to_nhwc(x, batch, c, hw, scale, shift, c, (bf16_t*)y, (hipStream_t)stream);
+}
+int mvd_op_nhwc_to_nchw(const void* x, int batch, int hw, int c, float* y, void* stream) {
+  return mvd_launch_nhwc_to_nchw_f32((const bf16_t*)x, batch, hw, c, y, (hipStream_t)stream);
+}
+int mvd_op_f32_to_bf16(const float* x, int64_t n, void* y, void* stream) {
+  return mvd_launch_f32_to_bf16(x, n, (bf16_t*)y, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,298 @@
+// bf16 MFMA GEMM / implicit-GEMM 3x3 convolution for gfx950 (MI355X).
+//
+//   out[M][N] = alpha * ( A[M][K] . W[N][K]^T + bias[N] + rowvec[batch(m)][N] ) + res[M][N]
+//
+// * A is either a dense token-major matrix (optionally the channel concat of two
+//   sources) or the *virtual* im2col matrix of an NHWC feature map (3x3, pad 1, stride
+//   1/2, optional fused nearest-2x upsample).  Up to two K segments are accumulated into
+//   the same tile, which fuses a ResnetBlock2D's conv2 with its 1x1 conv_shortcut and an
+//   attention out-projection with the adapter's to_out_ref.
+// * W is [N][K] with K contiguous (the nn.Linear layout; conv weights are packed
+//   [Cout][ky][kx][Cin] by the host).
+// * v_mfma_f32_16x16x32_bf16 with the roles swapped (W rows feed the MFMA "A" operand) so
+//   each lane ends up with 4 consecutive output channels of one row -> 8-byte stores.
+// * Tiles are staged through LDS in 64-wide K slabs, XOR-swizzled at 16-byte granularity
+//   ((row>>1)&7) so both the staging ds_write_b128 and the fragment ds_read_b128 are
+//   bank-conflict free; double-buffered, global loads for slab t+1 are issued before the
+//   MFMAs of slab t and written to LDS after them (one barrier per slab).
+// * blockIdx -> tile mapping is XCD-aware: consecutive tiles (same A rows, different N
+//   tile) land on the same XCD so the A slab is fetched from HBM once per XCD L2.
+#include "kernels.h"
+
+namespace {
+
+template <int BM_, int BN_, int WM_, int WN_>
+struct Cfg {
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+  static constexpr int NT = 64 * WM * WN;
+  static constexpr int WTM = BM / WM, WTN = BN / WN;
+  static constexpr int TM = WTM / 16, TN = WTN / 16;
+  static constexpr int A_CHUNKS = BM * 8, B_CHUNKS = BN * 8;
+  static constexpr int A_IT = (A_CHUNKS + NT - 1) / NT;
+  static constexpr int B_IT = (B_CHUNKS + NT - 1) / NT;
+  static constexpr int ROWS_PER_IT = NT / 8;
+  static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+  static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+  static_assert(WTM % 16 == 0 && WTN % 16 == 0, "wave tile must be a multiple of the MFMA tile");
+  static_assert(A_CHUNKS % NT == 0, "A slab must divide evenly over the threads");
+};
+
+MVD_DEVINL int swz_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+struct KState {  // position of the next K slab in the (segmented) A operand
+  int seg, tap, cc;
+};
+
+template <class C>
+__global__ __launch_bounds__(C::NT) void gemm_kernel(const MvdGemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / C::WN, wn = wave % C::WN;
+  const int ntn = a.N / C::BN;
+  const int ntm = (a.M + C::BM - 1) / C::BM;
+  const int t = xcd_remap(blockIdx.x, ntn * ntm);
+  const int m0 = (t / ntn) * C::BM, n0 = (t % ntn) * C::BN;
+  const int kc = tid & 7;
+  const int lrow = tid >> 3;
+
+  // per-thread A row descriptors
+  int a_m[C::A_IT], a_pb[C::A_IT], a_iy[C::A_IT], a_ix[C::A_IT];
+  const bool any_conv = (a.seg[0].mode == MVD_A_CONV3) || (a.nseg > 1 && a.seg[1].mode == MVD_A_CONV3);
+#pragma unroll
+  for (int i = 0; i < C::A_IT; ++i) {
+    int m = m0 + lrow + i * C::ROWS_PER_IT;
+    m = m < a.M ? m : a.M - 1;
+    a_m[i] = m;
+    a_pb[i] = 0; a_iy[i] = 0; a_ix[i] = 0;
+    if (any_conv) {
+      const MvdASeg& cs = (a.seg[0].mode == MVD_A_CONV3) ? a.seg[0] : a.seg[1];
+      const int b = m / a.rows_per_batch;
+      const int rem = m - b * a.rows_per_batch;
+      const int oy = rem / a.outW, ox = rem - oy * a.outW;
+      a_pb[i] = b * cs.inH * cs.inW;
+      a_iy[i] = oy * cs.stride - 1;
+      a_ix[i] = ox * cs.stride - 1;
+    }
+  }
+
+  u32x4 ra[C::A_IT], rb[C::B_IT];
+  KState ks{0, 0, 0};
+
+  auto load_a = [&]() {
+    const MvdASeg& sg = a.seg[ks.seg];
+    if (sg.mode == MVD_A_DENSE) {
+      const bool first = ks.cc < sg.c0;
+      const bf16_t* base = first ? sg.p0 : sg.p1;
+      const int ld = first ? sg.c0 : sg.c1;
+      const int col = (first ? ks.cc : ks.cc - sg.c0) + kc * 8;
+#pragma unroll
+      for (int i = 0; i < C::A_IT; ++i)
+        ra[i] = *reinterpret_cast<const u32x4*>(base + (size_t)a_m[i] * ld + col);
+    } else {
+      const int dy = ks.tap / 3, dx = ks.tap - dy * 3;
+      const int limH = sg.ups ? 2 * sg.inH : sg.inH, limW = sg.ups ? 2 * sg.inW : sg.inW;
+      const int col = ks.cc + kc * 8;
+#pragma unroll
+      for (int i = 0; i < C::A_IT; ++i) {
+        const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
+        const bool ok = (unsigned)iy < (unsigned)limH && (unsigned)ix < (unsigned)limW;
+        const int sy = sg.ups ? (iy >> 1) : iy, sx = sg.ups ? (ix >> 1) : ix;
+        const bf16_t* p = sg.p0 + (size_t)(a_pb[i] + sy * sg.inW + sx) * sg.c0 + col;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (ok) v = *reinterpret_cast<const u32x4*>(p);
+        ra[i] = v;
+      }
+    }
+    // advance to the next slab
+    ks.cc += 64;
+    const int lim = (sg.mode == MVD_A_DENSE) ? sg.c0 + sg.c1 : sg.c0;
+    if (ks.cc >= lim) {
+      ks.cc = 0;
+      if (sg.mode == MVD_A_DENSE || ++ks.tap == 9) { ks.tap = 0; ks.seg++; }
+    }
+  };
+  auto load_b = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < C::B_IT; ++i) {
+      const int row = lrow + i * C::ROWS_PER_IT;
+      if (C::B_CHUNKS % C::NT == 0 || row < C::BN)
+        rb[i] = *reinterpret_cast<const u32x4*>(a.W + (size_t)(n0 + row) * a.Ktot + kt * 64 + kc * 8);
+    }
+  };
+  auto store_stage = [&](int st) {
+    unsigned char* sa = smem + st * C::STAGE_BYTES;
+    unsigned char* sb = sa + C::A_BYTES;
+#pragma unroll
+    for (int i = 0; i < C::A_IT; ++i)
+      *reinterpret_cast<u32x4*>(sa + swz_off(lrow + i * C::ROWS_PER_IT, kc)) = ra[i];
+#pragma unroll
+    for (int i = 0; i < C::B_IT; ++i) {
+      const int row = lrow + i * C::ROWS_PER_IT;
+      if (C::B_CHUNKS % C::NT == 0 || row < C::BN) *reinterpret_cast<u32x4*>(sb + swz_off(row, kc)) = rb[i];
+    }
+  };
+
+  f32x4 acc[C::TM][C::TN];
+#pragma unroll
+  for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < C::TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = a.Ktot / 64;
+  load_a();
+  load_b(0);
+  store_stage(0);
+  __syncthreads();
+
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nkt;
+    if (more) { load_a(); load_b(kt + 1); }
+    const unsigned char* sa = smem + cur * C::STAGE_BYTES;
+    const unsigned char* sb = sa + C::A_BYTES;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8 af[C::TM], wf[C::TN];
+#pragma unroll
+      for (int i = 0; i < C::TM; ++i)
+        af[i] = *reinterpret_cast<const bf16x8*>(sa + swz_off(wm * C::WTM + i * 16 + fr, s2 * 4 + fq));
+#pragma unroll
+      for (int j = 0; j < C::TN; ++j)
+        wf[j] = *reinterpret_cast<const bf16x8*>(sb + swz_off(wn * C::WTN + j * 16 + fr, s2 * 4 + fq));
+#pragma unroll
+      for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_stage(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ------------------------------------------------------------------ epilogue
+  // lane holds out[m][n..n+3]: m = tile row (lane&15), n = 4*(lane>>4) + reg
+  const float alpha = a.alpha;
+#pragma unroll
+  for (int i = 0; i < C::TM; ++i) {
+    const int m = m0 + wm * C::WTM + i * 16 + fr;
+    if (m >= a.M) continue;
+    const float* rv = nullptr;
+    if (a.rowvec) rv = a.rowvec + (size_t)(m / a.rows_per_batch) * a.ld_rowvec;
+    if (!a.geglu) {
+#pragma unroll
+      for (int j = 0; j < C::TN; ++j) {
+        const int n = n0 + wn * C::WTN + j * 16 + fq * 4;
+        f32x4 v = acc[i][j];
+        if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
+        if (rv) v += *reinterpret_cast<const f32x4*>(rv + n);
+        v *= alpha;
+        if (a.res) {
+          const u32x2 r = *reinterpret_cast<const u32x2*>(a.res + (size_t)m * a.ldres + n);
+          v[0] += bflo(r[0]); v[1] += bfhi(r[0]); v[2] += bflo(r[1]); v[3] += bfhi(r[1]);
+        }
+        if (a.out_f32) {
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + (size_t)m * a.ldo + n) = v;
+        } else {
+          u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+          *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.ldo + n) = o;
+        }
+      }
+    } else {
+      if constexpr (C::TN % 2 == 0) {
+#pragma unroll
+        for (int j = 0; j < C::TN; j += 2) {
+          const int nv = n0 + wn * C::WTN + j * 16 + fq * 4;  // packed index of the value rows
+          f32x4 v = acc[i][j], g = acc[i][j + 1];
+          if (a.bias) {
+            v += *reinterpret_cast<const f32x4*>(a.bias + nv);
+            g += *reinterpret_cast<const f32x4*>(a.bias + nv + 16);
+          }
+          const int no = (n0 + wn * C::WTN) / 2 + (j / 2) * 16 + fq * 4;
+          u32x2 o = {pack2bf(v[0] * gelu_erf_f(g[0]), v[1] * gelu_erf_f(g[1])),
+                     pack2bf(v[2] * gelu_erf_f(g[2]), v[3] * gelu_erf_f(g[3]))};
+          *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.ldo + no) = o;
+        }
+      }
+    }
+  }
+}
+
+struct CfgInfo { int bm, bn, tn_even; };
+
+template <class C>
+int launch_cfg(const MvdGemmArgs& a, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<C>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    if (e != hipSuccess) { mvd_set_error("gemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return -2; }
+    attr_set = true;
+  }
+  const int ntm = (a.M + C::BM - 1) / C::BM, ntn = a.N / C::BN;
+  hipLaunchKernelGGL(gemm_kernel<C>, dim3(ntm * ntn), dim3(C::NT), C::LDS_BYTES, s, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { mvd_set_error("gemm launch: %s", hipGetErrorString(e)); return -3; }
+  return 0;
+}
+
+using C0 = Cfg<256, 160, 4, 2>;
+using C1 = Cfg<256, 128, 4, 2>;
+using C2 = Cfg<128, 160, 2, 2>;
+using C3 = Cfg<128, 128, 2, 2>;
+using C4 = Cfg<128, 64, 2, 2>;
+using C5 = Cfg<64, 64, 2, 2>;
+const CfgInfo kCfgs[] = {{256, 160, 0}, {256, 128, 1}, {128, 160, 0}, {128, 128, 1}, {128, 64, 1}, {64, 64, 1}};
+constexpr int kNumCfgs = 6;
+
+}  // namespace
+
+extern "C" int mvd_gemm_num_configs(void) { return kNumCfgs; }
+
+int mvd_launch_gemm(const MvdGemmArgs& a, hipStream_t s, int force_cfg) {
+  // ---- host-side shape validation: a wrong shape must never reach the kernel
+  if (a.M <= 0 || a.N <= 0 || a.Ktot <= 0 || a.nseg < 1 || a.nseg > 2) { mvd_set_error("gemm: bad dims M=%d N=%d K=%d nseg=%d", a.M, a.N, a.Ktot, a.nseg); return -1; }
+  int ksum = 0;
+  for (int i = 0; i < a.nseg; ++i) {
+    const MvdASeg& g = a.seg[i];
+    if (g.mode == MVD_A_DENSE) {
+      if (g.c0 % 64 || g.c1 % 64 || g.ksize != g.c0 + g.c1 || !g.p0 || (g.c1 && !g.p1)) { mvd_set_error("gemm: bad dense segment %d (c0=%d c1=%d ksize=%d)", i, g.c0, g.c1, g.ksize); return -1; }
+    } else if (g.mode == MVD_A_CONV3) {
+      if (g.c0 % 64 || g.c1 != 0 || g.ksize != 9 * g.c0 || !g.p0 || (g.stride != 1 && g.stride != 2) || (g.ups && g.stride != 1)) { mvd_set_error("gemm: bad conv segment %d", i); return -1; }
+      const int eh = g.ups ? 2 * g.inH : (g.stride == 2 ? (g.inH + 1) / 2 : g.inH);
+      const int ew = g.ups ? 2 * g.inW : (g.stride == 2 ? (g.inW + 1) / 2 : g.inW);
+      if (eh != a.outH || ew != a.outW || a.rows_per_batch != a.outH * a.outW || a.M % a.rows_per_batch) { mvd_set_error("gemm: conv geometry mismatch (in %dx%d out %dx%d rpb %d M %d)", g.inH, g.inW, a.outH, a.outW, a.rows_per_batch, a.M); return -1; }
+    } else { mvd_set_error("gemm: bad mode"); return -1; }
+    ksum += g.ksize;
+  }
+  if (a.nseg == 2 && a.seg[0].mode == MVD_A_CONV3 && a.seg[1].mode == MVD_A_CONV3) { mvd_set_error("gemm: two conv segments unsupported"); return -1; }
+  if (ksum != a.Ktot) { mvd_set_error("gemm: segment K sum %d != Ktot %d", ksum, a.Ktot); return -1; }
+  if (a.rows_per_batch <= 0) { mvd_set_error("gemm: rows_per_batch must be > 0"); return -1; }
+  if (a.N % 64) { mvd_set_error("gemm: N=%d must be a multiple of 64", a.N); return -1; }
+  if (a.geglu && (a.out_f32 || a.res || a.rowvec)) { mvd_set_error("gemm: unsupported GEGLU epilogue combination"); return -1; }
+  const int on = a.geglu ? a.N / 2 : a.N;
+  if (a.ldo < on || (a.ldo % 4) || (a.res && (a.ldres % 4))) { mvd_set_error("gemm: bad leading dims"); return -1; }
+
+  int cfg = force_cfg;
+  if (cfg < 0) {
+    // largest tile that still yields >= ~2 blocks per CU; otherwise the config with most blocks
+    long best_blocks = -1;
+    for (int c = 0; c < kNumCfgs; ++c) {
+      if (a.N % kCfgs[c].bn) continue;
+      if (a.geglu && !kCfgs[c].tn_even) continue;
+      const long blocks = (long)((a.M + kCfgs[c].bm - 1) / kCfgs[c].bm) * (a.N / kCfgs[c].bn);
+      if (blocks >= 480) { cfg = c; break; }
+      if (blocks > best_blocks) { best_blocks = blocks; cfg = c; }
+    }
+  }
+  if (cfg < 0 || cfg >= kNumCfgs || a.N % kCfgs[cfg].bn || (a.geglu && !kCfgs[cfg].tn_even)) { mvd_set_error("gemm: no tile config for N=%d geglu=%d cfg=%d", a.N, a.geglu, cfg); return -1; }
+  switch (cfg) {
+    case 0: return launch_cfg<C0>(a, s);
+    case 1: return launch_cfg<C1>(a, s);
+    case 2: return launch_cfg<C2>(a, s);
+    case 3: return launch_cfg<C3>(a, s);
+    case 4: return launch_cfg<C4>(a, s);
+    default: return launch_cfg<C5>(a, s);
+  }
+}

@@ -1,0 +1,105 @@
+// Launcher interface of the hand-written gfx950 kernels (internal; the public C ABI is
+// include/mvd_hip.h).  All tensors are device pointers; activations are token-major
+// ("NHWC"): [batch][pixel][channel] bf16.  Every launcher returns 0 or a negative error
+// code and records a message retrievable through mvd_last_error().
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "common.h"
+
+// ---------------------------------------------------------------- GEMM / implicit conv
+enum { MVD_A_DENSE = 0, MVD_A_CONV3 = 1 };
+
+struct MvdASeg {          // one K segment of the A operand
+  const bf16_t* p0;       // source 0 ([rows][c0] dense, or NHWC feature map)
+  const bf16_t* p1;       // optional source 1 (channel concat), dense mode only
+  int c0, c1;             // channels of each source (c1 == 0: single source)
+  int mode;               // MVD_A_DENSE / MVD_A_CONV3
+  int ksize;              // K extent: dense c0+c1, conv 9*c0
+  int inH, inW;           // conv: stored input spatial size
+  int stride;             // conv: 1 or 2
+  int ups;                // conv: 1 = nearest 2x upsample fused in front of the conv
+};
+
+struct MvdGemmArgs {
+  MvdASeg seg[2];
+  int nseg;
+  const bf16_t* W;        // [N][Ktot] bf16, K contiguous
+  int M, N, Ktot;
+  int rows_per_batch;     // pixels per batch element (conv geometry + per-batch epilogue vector)
+  int outH, outW;         // conv output spatial size
+  const float* bias;      // [N] fp32 or null
+  const float* rowvec;    // [batch][ld_rowvec] fp32 added per batch (time-embedding projection) or null
+  int ld_rowvec;
+  const bf16_t* res;      // residual [M][ldres] bf16 or null
+  int ldres;
+  float alpha;            // out = alpha*(acc + bias + rowvec) + res
+  int geglu;              // 1: W rows interleaved (16 value | 16 gate); out = value*gelu(gate), width N/2
+  void* out;
+  int ldo;
+  int out_f32;            // 1: fp32 output, else bf16
+};
+
+int mvd_launch_gemm(const MvdGemmArgs& a, hipStream_t s, int force_cfg = -1);
+
+// ---------------------------------------------------------------- attention (head_dim 64)
+struct MvdAttnProblem {
+  const bf16_t* q; const bf16_t* k; const bf16_t* v; bf16_t* o;
+  int ldq, ldk, ldv, ldo;         // row strides in elements
+  int64_t bsq, bsk, bsv, bso;     // batch strides in elements
+  int nq, nk;                     // tokens per batch element
+};
+struct MvdAttnArgs {
+  MvdAttnProblem p[2];            // up to two independent problems in one launch
+  int nprob;
+  int batch, heads;
+  float scale;                    // softmax scale (1/sqrt(64))
+};
+int mvd_launch_attention(const MvdAttnArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- normalisation
+// GroupNorm over NHWC with optional 2-source channel concat; y = gn(x)*gamma+beta, optional SiLU.
+// ws: fp32 scratch of at least batch*MVD_GN_MAXCHUNK*groups*2 floats.
+#define MVD_GN_MAXCHUNK 64
+int mvd_launch_groupnorm(const bf16_t* x0, const bf16_t* x1, int c0, int c1, int batch, int hw, int groups,
+                         float eps, const float* gamma, const float* beta, int silu, bf16_t* y, float* ws,
+                         hipStream_t s);
+int mvd_launch_layernorm(const bf16_t* x, int rows, int c, float eps, const float* gamma, const float* beta,
+                         bf16_t* y, hipStream_t s);
+// Q2 reference normalisation: per pixel over (batch, channel), unbiased std, clamp 1e-6, *0.5
+int mvd_launch_refnorm(const bf16_t* x, int batch, int hw, int c, bf16_t* y, hipStream_t s);
+
+// ---------------------------------------------------------------- elementwise / small ops
+// NCHW fp32 -> NHWC bf16 with optional FiLM (scale/shift fp32 [batch][c])
+int mvd_launch_nchw_to_nhwc(const float* x, int batch, int c, int hw, const float* scale, const float* shift,
+                            int ld_ss, bf16_t* y, hipStream_t s);
+int mvd_launch_film(const bf16_t* x, int batch, int hw, int c, const float* scale, const float* shift, int ld_ss,
+                    bf16_t* y, hipStream_t s);
+// conv_in: 3x3 pad 1, tiny Cin (<=8) -> Cout, NHWC bf16 in/out, weights fp32 [Cout][3][3][Cin]
+int mvd_launch_conv_in(const bf16_t* x, int batch, int h, int w, int cin, const float* wt, const float* bias,
+                       int cout, bf16_t* y, hipStream_t s);
+// conv_out: 3x3 pad 1, C -> tiny Cout (<=8), NHWC bf16 in, NCHW fp32 out, weights bf16 [Cout][3][3][C]
+int mvd_launch_conv_out(const bf16_t* x, int batch, int h, int w, int c, const bf16_t* wt, const float* bias,
+                        int cout, float* y, hipStream_t s);
+// fp32 -> bf16 copy
+int mvd_launch_f32_to_bf16(const float* x, int64_t n, bf16_t* y, hipStream_t s);
+int mvd_launch_nhwc_to_nchw_f32(const bf16_t* x, int batch, int hw, int c, float* y, hipStream_t s);
+
+// skinny fp32 linear: y[b][n] = act_out( sum_k act_in(x[b][k]) * W[n][k] + bias[n] ), b < 256
+// W is fp32 (wbf16 == 0) or bf16 (wbf16 == 1).  act: 0 none, 1 SiLU
+int mvd_launch_skinny_linear(const float* x, int ldx, int batch, int k, const void* w, int wbf16, const float* bias,
+                             int n, int act_in, float* y, int ldy, hipStream_t s);
+// row LayerNorm in fp32 with optional SiLU
+int mvd_launch_layernorm_f32(const float* x, int rows, int c, float eps, const float* gamma, const float* beta,
+                             int silu, float* y, hipStream_t s);
+// sinusoidal timestep embedding [cos|sin] (diffusers flip_sin_to_cos=True, freq_shift 0)
+int mvd_launch_timestep_embedding(const float* t, int batch, int dim, float* y, hipStream_t s);
+// camera front end: relative pose + Fourier features: cams [batch][rows(3|4)][4] fp32 ->
+// rflat [batch][9], enc [batch][6*nfreq] (before the random projection)
+int mvd_launch_camera_features(const float* src, const float* tgt, int batch, int cam_rows, int nfreq,
+                               float max_freq, float* rflat, float* enc, hipStream_t s);
+// FiLM post-processing: raw [batch][2*dim] -> scale = 2*sigmoid(raw[:dim])*k, shift = raw[dim:]*k
+int mvd_launch_film_params(const float* raw, int batch, int dim, float strength, float* scale, float* shift,
+                           hipStream_t s);
+
+void mvd_set_error(const char* fmt, ...);

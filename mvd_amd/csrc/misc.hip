@@ -1,0 +1,306 @@
+// Small / elementwise kernels of the MVD hot path: layout conversion, FiLM, conv_in,
+// conv_out, timestep + camera embeddings and the skinny fp32 linears of the camera MLPs.
+#include <stdarg.h>
+#include <stdio.h>
+#include "kernels.h"
+
+static thread_local char g_err[512] = "";
+void mvd_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* mvd_last_error(void) { return g_err; }
+
+namespace {
+
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, int c, int hw, const float* __restrict__ scale,
+                                    const float* __restrict__ shift, int ld_ss, bf16_t* __restrict__ y, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over (b, p, ch)
+  if (i >= total) return;
+  const int ch = i % c;
+  const long bp = i / c;
+  const int p = bp % hw;
+  const int b = bp / hw;
+  float v = x[((size_t)b * c + ch) * hw + p];
+  if (scale) v = v * scale[(size_t)b * ld_ss + ch] + shift[(size_t)b * ld_ss + ch];
+  y[i] = f2bf(v);
+}
+
+__global__ void nhwc_to_nchw_f32_kernel(const bf16_t* __restrict__ x, int hw, int c, float* __restrict__ y, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over (b, ch, p) output order
+  if (i >= total) return;
+  const int p = i % hw;
+  const long bc = i / hw;
+  const int ch = bc % c;
+  const int b = bc / c;
+  y[i] = bf2f(x[((size_t)b * hw + p) * c + ch]);
+}
+
+__global__ void film_kernel(const bf16_t* __restrict__ x, int hw, int c, const float* __restrict__ scale,
+                            const float* __restrict__ shift, int ld_ss, bf16_t* __restrict__ y, long nvec) {
+  const int vec = c >> 3;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < nvec; e += (long)gridDim.x * blockDim.x) {
+    const int v = e % vec;
+    const long bp = e / vec;
+    const int b = bp / hw;
+    const u32x4 in = *reinterpret_cast<const u32x4*>(x + e * 8);
+    const float* sc = scale + (size_t)b * ld_ss + v * 8;
+    const float* sf = shift + (size_t)b * ld_ss + v * 8;
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      o[j] = pack2bf(fmaf(bflo(in[j]), sc[2 * j], sf[2 * j]), fmaf(bfhi(in[j]), sc[2 * j + 1], sf[2 * j + 1]));
+    *reinterpret_cast<u32x4*>(y + e * 8) = o;
+  }
+}
+
+// conv_in: thread = (pixel, 8 output channels)
+__global__ void conv_in_kernel(const bf16_t* __restrict__ x, int h, int w, int cin, const float* __restrict__ wt,
+                               const float* __restrict__ bias, int cout, bf16_t* __restrict__ y, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int ng = cout >> 3;
+  const int g = i % ng;
+  const long bp = i / ng;
+  const int hw = h * w;
+  const int p = bp % hw;
+  const int b = bp / hw;
+  const int oy = p / w, ox = p % w;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = bias[g * 8 + j];
+  for (int tap = 0; tap < 9; ++tap) {
+    const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+    if ((unsigned)iy >= (unsigned)h || (unsigned)ix >= (unsigned)w) continue;
+    const bf16_t* xp = x + ((size_t)b * hw + iy * w + ix) * cin;
+    for (int ci = 0; ci < cin; ++ci) {
+      const float xv = bf2f(xp[ci]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv, wt[((size_t)(g * 8 + j) * 9 + tap) * cin + ci], acc[j]);
+    }
+  }
+  u32x4 o = {pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]), pack2bf(acc[4], acc[5]), pack2bf(acc[6], acc[7])};
+  *reinterpret_cast<u32x4*>(y + bp * cout + g * 8) = o;
+}
+
+// conv_out: one wave per output pixel, lanes split K = 9*C in 16-byte chunks
+__global__ __launch_bounds__(256) void conv_out_kernel(const bf16_t* __restrict__ x, int batch, int h, int w, int c,
+                                                        const bf16_t* __restrict__ wt, const float* __restrict__ bias,
+                                                        int cout, float* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const long pix = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int hw = h * w;
+  if (pix >= (long)batch * hw) return;
+  const int b = pix / hw, p = pix % hw;
+  const int oy = p / w, ox = p % w;
+  const int vec = c >> 3;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int q = lane; q < 9 * vec; q += 64) {
+    const int tap = q / vec, v = q % vec;
+    const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+    if ((unsigned)iy >= (unsigned)h || (unsigned)ix >= (unsigned)w) continue;
+    const u32x4 xv = *reinterpret_cast<const u32x4*>(x + ((size_t)b * hw + iy * w + ix) * c + v * 8);
+#pragma unroll
+    for (int co = 0; co < 8; ++co) {
+      if (co < cout) {
+        const u32x4 wv = *reinterpret_cast<const u32x4*>(wt + ((size_t)co * 9 + tap) * c + v * 8);
+        float a = acc[co];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          a = fmaf(bflo(xv[j]), bflo(wv[j]), a);
+          a = fmaf(bfhi(xv[j]), bfhi(wv[j]), a);
+        }
+        acc[co] = a;
+      }
+    }
+  }
+#pragma unroll
+  for (int co = 0; co < 8; ++co) {
+    if (co < cout) {
+      const float t = wave_sum(acc[co]);
+      if (lane == 0) y[((size_t)b * cout + co) * hw + p] = t + bias[co];
+    }
+  }
+}
+
+__global__ void f32_to_bf16_kernel(const float* __restrict__ x, long n, bf16_t* __restrict__ y) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = f2bf(x[i]);
+}
+
+// skinny linear: one wave per output feature; batch processed in chunks of 8
+template <bool WBF16>
+__global__ __launch_bounds__(256) void skinny_linear_kernel(const float* __restrict__ x, int ldx, int batch, int k,
+                                                             const void* __restrict__ wv, const float* __restrict__ bias,
+                                                             int n, int act_in, float* __restrict__ y, int ldy) {
+  const int lane = threadIdx.x & 63;
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (o >= n) return;
+  for (int b0 = 0; b0 < batch; b0 += 8) {
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int kk = lane; kk < k; kk += 64) {
+      float wgt;
+      if (WBF16) wgt = bf2f(reinterpret_cast<const bf16_t*>(wv)[(size_t)o * k + kk]);
+      else wgt = reinterpret_cast<const float*>(wv)[(size_t)o * k + kk];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (b0 + j < batch) {
+          float xv = x[(size_t)(b0 + j) * ldx + kk];
+          if (act_in == 1) xv = silu_f(xv);
+          acc[j] = fmaf(xv, wgt, acc[j]);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (b0 + j < batch) {
+        const float t = wave_sum(acc[j]);
+        if (lane == 0) y[(size_t)(b0 + j) * ldy + o] = t + (bias ? bias[o] : 0.f);
+      }
+    }
+  }
+}
+
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, int dim, float* __restrict__ y) {
+  const int b = blockIdx.x;
+  const int half = dim >> 1;
+  for (int i = threadIdx.x; i < half; i += blockDim.x) {
+    const float f = expf(-9.210340371976184f * (float)i / (float)half);
+    const float ang = t[b] * f;
+    y[(size_t)b * dim + i] = cosf(ang);
+    y[(size_t)b * dim + half + i] = sinf(ang);
+  }
+}
+
+// relative pose + Fourier features (camera_encoder.py:107-151 of the reference)
+__global__ void camera_features_kernel(const float* __restrict__ src, const float* __restrict__ tgt, int cam_rows,
+                                       int nfreq, float log_max_freq, float* __restrict__ rflat,
+                                       float* __restrict__ enc) {
+  const int b = blockIdx.x;
+  __shared__ float R[9], T[3];
+  const float* s = src + (size_t)b * cam_rows * 4;
+  const float* g = tgt + (size_t)b * cam_rows * 4;
+  if (threadIdx.x < 9) {
+    const int i = threadIdx.x / 3, j = threadIdx.x % 3;
+    float a = 0.f;
+    for (int kk = 0; kk < 3; ++kk) a += g[i * 4 + kk] * s[j * 4 + kk];  // tR . sR^T
+    R[threadIdx.x] = a;
+    rflat[(size_t)b * 9 + threadIdx.x] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int i = threadIdx.x;
+    float a = g[i * 4 + 3];
+    for (int kk = 0; kk < 3; ++kk) a -= R[i * 3 + kk] * s[kk * 4 + 3];
+    T[i] = a;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 3 * nfreq; e += blockDim.x) {
+    const int ax = e / nfreq, i = e % nfreq;
+    const float f = expf(log_max_freq * (float)i / (float)(nfreq - 1));
+    const float ang = T[ax] * f;
+    enc[(size_t)b * 6 * nfreq + ax * 2 * nfreq + i] = sinf(ang);
+    enc[(size_t)b * 6 * nfreq + ax * 2 * nfreq + nfreq + i] = cosf(ang);
+  }
+}
+
+__global__ void film_params_kernel(const float* __restrict__ raw, int dim, float strength, float* __restrict__ scale,
+                                   float* __restrict__ shift, int total) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int b = i / dim, ch = i % dim;
+  const float s = raw[(size_t)b * 2 * dim + ch], t = raw[(size_t)b * 2 * dim + dim + ch];
+  scale[i] = 2.0f * strength / (1.0f + expf(-s));
+  shift[i] = t * strength;
+}
+
+int check(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { mvd_set_error("%s launch: %s", what, hipGetErrorString(e)); return -3; }
+  return 0;
+}
+inline int nblk(long n, int t) { return (int)((n + t - 1) / t); }
+
+}  // namespace
+
+int mvd_launch_nchw_to_nhwc(const float* x, int batch, int c, int hw, const float* scale, const float* shift, int ld_ss,
+                            bf16_t* y, hipStream_t s) {
+  if (!x || !y || batch <= 0 || c <= 0 || hw <= 0 || ((scale == nullptr) != (shift == nullptr))) { mvd_set_error("nchw_to_nhwc: bad arguments"); return -1; }
+  const long total = (long)batch * c * hw;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, x, c, hw, scale, shift, ld_ss, y, total);
+  return check("nchw_to_nhwc");
+}
+
+int mvd_launch_nhwc_to_nchw_f32(const bf16_t* x, int batch, int hw, int c, float* y, hipStream_t s) {
+  if (!x || !y || batch <= 0 || c <= 0 || hw <= 0) { mvd_set_error("nhwc_to_nchw: bad arguments"); return -1; }
+  const long total = (long)batch * c * hw;
+  hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, x, hw, c, y, total);
+  return check("nhwc_to_nchw");
+}
+
+int mvd_launch_film(const bf16_t* x, int batch, int hw, int c, const float* scale, const float* shift, int ld_ss,
+                    bf16_t* y, hipStream_t s) {
+  if (!x || !y || !scale || !shift || batch <= 0 || hw <= 0 || c <= 0 || (c % 8)) { mvd_set_error("film: bad arguments"); return -1; }
+  const long nvec = (long)batch * hw * (c / 8);
+  int grid = nblk(nvec, 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(film_kernel, dim3(grid), dim3(256), 0, s, x, hw, c, scale, shift, ld_ss, y, nvec);
+  return check("film");
+}
+
+int mvd_launch_conv_in(const bf16_t* x, int batch, int h, int w, int cin, const float* wt, const float* bias, int cout,
+                       bf16_t* y, hipStream_t s) {
+  if (!x || !y || !wt || !bias || batch <= 0 || h <= 0 || w <= 0 || cin <= 0 || cin > 16 || (cout % 8)) { mvd_set_error("conv_in: bad arguments"); return -1; }
+  const long total = (long)batch * h * w * (cout / 8);
+  hipLaunchKernelGGL(conv_in_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, x, h, w, cin, wt, bias, cout, y, total);
+  return check("conv_in");
+}
+
+int mvd_launch_conv_out(const bf16_t* x, int batch, int h, int w, int c, const bf16_t* wt, const float* bias, int cout,
+                        float* y, hipStream_t s) {
+  if (!x || !y || !wt || !bias || batch <= 0 || h <= 0 || w <= 0 || (c % 8) || cout <= 0 || cout > 8) { mvd_set_error("conv_out: bad arguments"); return -1; }
+  const long pix = (long)batch * h * w;
+  hipLaunchKernelGGL(conv_out_kernel, dim3(nblk(pix, 4)), dim3(256), 0, s, x, batch, h, w, c, wt, bias, cout, y);
+  return check("conv_out");
+}
+
+int mvd_launch_f32_to_bf16(const float* x, int64_t n, bf16_t* y, hipStream_t s) {
+  if (!x || !y || n <= 0) { mvd_set_error("f32_to_bf16: bad arguments"); return -1; }
+  int grid = nblk(n, 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid), dim3(256), 0, s, x, (long)n, y);
+  return check("f32_to_bf16");
+}
+
+int mvd_launch_skinny_linear(const float* x, int ldx, int batch, int k, const void* w, int wbf16, const float* bias, int n,
+                             int act_in, float* y, int ldy, hipStream_t s) {
+  if (!x || !w || !y || batch <= 0 || batch > 4096 || k <= 0 || n <= 0 || ldx < k || ldy < n) { mvd_set_error("skinny_linear: bad arguments"); return -1; }
+  if (wbf16) hipLaunchKernelGGL(skinny_linear_kernel<true>, dim3(nblk(n, 4)), dim3(256), 0, s, x, ldx, batch, k, w, bias, n, act_in, y, ldy);
+  else hipLaunchKernelGGL(skinny_linear_kernel<false>, dim3(nblk(n, 4)), dim3(256), 0, s, x, ldx, batch, k, w, bias, n, act_in, y, ldy);
+  return check("skinny_linear");
+}
+
+int mvd_launch_timestep_embedding(const float* t, int batch, int dim, float* y, hipStream_t s) {
+  if (!t || !y || batch <= 0 || dim <= 0 || (dim & 1)) { mvd_set_error("timestep_embedding: bad arguments"); return -1; }
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3(batch), dim3(128), 0, s, t, dim, y);
+  return check("timestep_embedding");
+}
+
+int mvd_launch_camera_features(const float* src, const float* tgt, int batch, int cam_rows, int nfreq, float max_freq,
+                               float* rflat, float* enc, hipStream_t s) {
+  if (!src || !tgt || !rflat || !enc || batch <= 0 || (cam_rows != 3 && cam_rows != 4) || nfreq < 2) { mvd_set_error("camera_features: bad arguments"); return -1; }
+  hipLaunchKernelGGL(camera_features_kernel, dim3(batch), dim3(256), 0, s, src, tgt, cam_rows, nfreq, logf(max_freq), rflat, enc);
+  return check("camera_features");
+}
+
+int mvd_launch_film_params(const float* raw, int batch, int dim, float strength, float* scale, float* shift, hipStream_t s) {
+  if (!raw || !scale || !shift || batch <= 0 || dim <= 0) { mvd_set_error("film_params: bad arguments"); return -1; }
+  const int total = batch * dim;
+  hipLaunchKernelGGL(film_params_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, raw, dim, strength, scale, shift, total);
+  return check("film_params");
+}

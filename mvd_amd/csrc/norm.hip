@@ -1,0 +1,294 @@
+// Normalisation kernels (HBM-bound, 16-byte vectorised): GroupNorm(+SiLU) over NHWC with an
+// optional two-source channel concat, LayerNorm, and the MVD reference-feature
+// normalisation (per pixel over batch x channel, attention.py:95-103 of the reference).
+#include "kernels.h"
+
+namespace {
+
+MVD_DEVINL void unpack8(const u32x4 v, float* f) {
+  f[0] = bflo(v[0]); f[1] = bfhi(v[0]); f[2] = bflo(v[1]); f[3] = bfhi(v[1]);
+  f[4] = bflo(v[2]); f[5] = bfhi(v[2]); f[6] = bflo(v[3]); f[7] = bfhi(v[3]);
+}
+MVD_DEVINL u32x4 pack8(const float* f) {
+  return u32x4{pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7])};
+}
+
+// ---------------------------------------------------------------- GroupNorm: partial sums
+// grid (nchunk, batch); block = vec*R threads (vec = C/8 channel vectors, R rows in flight).
+// Deterministic: per-thread channel sums -> LDS -> fixed-order per-group reduction.
+__global__ void gn_stats_kernel(const bf16_t* __restrict__ x0, const bf16_t* __restrict__ x1, int c0, int c1, int hw,
+                                int groups, int rows_per_chunk, int R, float* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];  // [R][C][2]
+  const int C = c0 + c1, vec = C >> 3;
+  const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+  const int v = threadIdx.x % vec, r = threadIdx.x / vec;
+  const int row0 = chunk * rows_per_chunk;
+  const int row1 = min(hw, row0 + rows_per_chunk);
+  const int ch = v * 8;
+  const bool first = ch < c0;
+  const bf16_t* src = first ? x0 + (size_t)b * hw * c0 + ch : x1 + (size_t)b * hw * c1 + (ch - c0);
+  const int ld = first ? c0 : c1;
+  float s[8], q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+  if (r < R) {
+    for (int row = row0 + r; row < row1; row += R) {
+      float f[8];
+      unpack8(*reinterpret_cast<const u32x4*>(src + (size_t)row * ld), f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s[j] += f[j]; q[j] = fmaf(f[j], f[j], q[j]); }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sh[(r * C + ch + j) * 2] = s[j];
+      sh[(r * C + ch + j) * 2 + 1] = q[j];
+    }
+  }
+  __syncthreads();
+  const int cg = C / groups;
+  if (threadIdx.x < groups * 2) {
+    const int g = threadIdx.x >> 1, which = threadIdx.x & 1;
+    float acc = 0.f;
+    for (int rr = 0; rr < R; ++rr)
+      for (int cc = 0; cc < cg; ++cc) acc += sh[(rr * C + g * cg + cc) * 2 + which];
+    ws[(((size_t)b * nchunk + chunk) * groups + g) * 2 + which] = acc;
+  }
+}
+
+// ---------------------------------------------------------------- GroupNorm: apply (+SiLU)
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x0, const bf16_t* __restrict__ x1,
+                                                        int c0, int c1, int hw, int groups, int nchunk_stats,
+                                                        float eps, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int silu,
+                                                        const float* __restrict__ ws, int rows_per_blk,
+                                                        bf16_t* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];  // mean[groups] rstd[groups] a[C] b[C]
+  const int C = c0 + c1, vec = C >> 3, cg = C / groups;
+  const int b = blockIdx.y;
+  float* s_mean = sh;
+  float* s_rstd = sh + groups;
+  float* s_a = sh + 2 * groups;
+  float* s_b = s_a + C;
+  if (threadIdx.x < groups) {
+    float s = 0.f, q = 0.f;
+    for (int ck = 0; ck < nchunk_stats; ++ck) {
+      s += ws[(((size_t)b * nchunk_stats + ck) * groups + threadIdx.x) * 2];
+      q += ws[(((size_t)b * nchunk_stats + ck) * groups + threadIdx.x) * 2 + 1];
+    }
+    const float n = (float)hw * (float)cg;
+    const float mean = s / n;
+    const float var = fmaxf(q / n - mean * mean, 0.f);
+    s_mean[threadIdx.x] = mean;
+    s_rstd[threadIdx.x] = rsqrtf(var + eps);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const int g = c / cg;
+    const float a = gamma[c] * s_rstd[g];
+    s_a[c] = a;
+    s_b[c] = beta[c] - s_mean[g] * a;
+  }
+  __syncthreads();
+  const int row0 = blockIdx.x * rows_per_blk;
+  const int nrow = min(hw, row0 + rows_per_blk) - row0;
+  const int total = nrow * vec;
+  for (int e = threadIdx.x; e < total; e += blockDim.x) {
+    const int row = row0 + e / vec, v = e % vec, ch = v * 8;
+    const bool first = ch < c0;
+    const bf16_t* src = first ? x0 + ((size_t)b * hw + row) * c0 + ch : x1 + ((size_t)b * hw + row) * c1 + (ch - c0);
+    float f[8];
+    unpack8(*reinterpret_cast<const u32x4*>(src), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float t = fmaf(f[j], s_a[ch + j], s_b[ch + j]);
+      f[j] = silu ? silu_f(t) : t;
+    }
+    *reinterpret_cast<u32x4*>(y + ((size_t)b * hw + row) * C + ch) = pack8(f);
+  }
+}
+
+// ---------------------------------------------------------------- LayerNorm (bf16 rows)
+// one wave per row, row kept in registers (C <= 64*8*MAXV), two-pass mean/variance.
+template <int MAXV>
+__global__ __launch_bounds__(256) void ln_kernel(const bf16_t* __restrict__ x, int rows, int c, float eps,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  bf16_t* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int vec = c >> 3;
+  float f[MAXV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int v = lane + i * 64;
+    if (v < vec) {
+      unpack8(*reinterpret_cast<const u32x4*>(x + (size_t)row * c + v * 8), f[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += f[i][j];
+    }
+  }
+  const float mean = wave_sum(s) / (float)c;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int v = lane + i * 64;
+    if (v < vec) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = f[i][j] - mean; q = fmaf(d, d, q); }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)c + eps);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int v = lane + i * 64;
+    if (v < vec) {
+      float o[8];
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + v * 8), g1 = *reinterpret_cast<const f32x4*>(gamma + v * 8 + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + v * 8), b1 = *reinterpret_cast<const f32x4*>(beta + v * 8 + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o[j] = (f[i][j] - mean) * rstd * g0[j] + b0[j];
+        o[j + 4] = (f[i][j + 4] - mean) * rstd * g1[j] + b1[j];
+      }
+      *reinterpret_cast<u32x4*>(y + (size_t)row * c + v * 8) = pack8(o);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- reference normalisation (Q2)
+// one workgroup per pixel; statistics over (batch, channel), unbiased std.
+__global__ __launch_bounds__(256) void refnorm_kernel(const bf16_t* __restrict__ x, int batch, int hw, int c,
+                                                      bf16_t* __restrict__ y) {
+  __shared__ float red[8];
+  const int p = blockIdx.x;
+  const int vec = c >> 3;
+  const int total = batch * vec;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  auto block_sum = [&](float v) -> float {
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+  };
+  float s = 0.f;
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int b = e / vec, v = e % vec;
+    float f[8];
+    unpack8(*reinterpret_cast<const u32x4*>(x + ((size_t)b * hw + p) * c + v * 8), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += f[j];
+  }
+  const float n = (float)batch * (float)c;
+  const float mean = block_sum(s) / n;
+  float q = 0.f;
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int b = e / vec, v = e % vec;
+    float f[8];
+    unpack8(*reinterpret_cast<const u32x4*>(x + ((size_t)b * hw + p) * c + v * 8), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float d = f[j] - mean; q = fmaf(d, d, q); }
+  }
+  const float var = block_sum(q) / (n - 1.0f);
+  const float k = 0.5f / fmaxf(sqrtf(var), 1e-6f);
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int b = e / vec, v = e % vec;
+    float f[8];
+    const size_t off = ((size_t)b * hw + p) * c + v * 8;
+    unpack8(*reinterpret_cast<const u32x4*>(x + off), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (f[j] - mean) * k;
+    *reinterpret_cast<u32x4*>(y + off) = pack8(f);
+  }
+}
+
+// ---------------------------------------------------------------- fp32 row LayerNorm (camera MLPs)
+__global__ __launch_bounds__(256) void ln_f32_kernel(const float* __restrict__ x, int c, float eps,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      int silu, float* __restrict__ y) {
+  __shared__ float red[8];
+  const int row = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  auto block_sum = [&](float v) -> float {
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+  };
+  const float* xr = x + (size_t)row * c;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < c; i += 256) s += xr[i];
+  const float mean = block_sum(s) / (float)c;
+  float q = 0.f;
+  for (int i = threadIdx.x; i < c; i += 256) { const float d = xr[i] - mean; q = fmaf(d, d, q); }
+  const float rstd = rsqrtf(block_sum(q) / (float)c + eps);
+  for (int i = threadIdx.x; i < c; i += 256) {
+    float t = (xr[i] - mean) * rstd * gamma[i] + beta[i];
+    y[(size_t)row * c + i] = silu ? silu_f(t) : t;
+  }
+}
+
+}  // namespace
+
+static int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { mvd_set_error("%s launch: %s", what, hipGetErrorString(e)); return -3; }
+  return 0;
+}
+
+int mvd_launch_groupnorm(const bf16_t* x0, const bf16_t* x1, int c0, int c1, int batch, int hw, int groups, float eps,
+                         const float* gamma, const float* beta, int silu, bf16_t* y, float* ws, hipStream_t s) {
+  const int C = c0 + c1;
+  if (!x0 || (c1 && !x1) || !y || !ws || !gamma || !beta || batch <= 0 || hw <= 0 || groups <= 0 || groups > 128 ||
+      (C % groups) || (c0 % 8) || (c1 % 8) || C > 8192) {
+    mvd_set_error("groupnorm: bad arguments (c0=%d c1=%d batch=%d hw=%d groups=%d)", c0, c1, batch, hw, groups);
+    return -1;
+  }
+  const int vec = C / 8;
+  if (vec > 1024) { mvd_set_error("groupnorm: C=%d too wide", C); return -1; }
+  const int R = vec >= 256 ? 1 : 256 / vec;
+  const int threads = ((vec * R + 63) / 64) * 64;
+  int nchunk = hw / 64;
+  nchunk = nchunk < 1 ? 1 : (nchunk > MVD_GN_MAXCHUNK ? MVD_GN_MAXCHUNK : nchunk);
+  const int rpc = (hw + nchunk - 1) / nchunk;
+  nchunk = (hw + rpc - 1) / rpc;
+  const size_t sh1 = (size_t)R * C * 2 * sizeof(float);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, batch), dim3(threads), sh1, s, x0, x1, c0, c1, hw, groups, rpc, R, ws);
+  if (int r = check_launch("gn_stats")) return r;
+  // apply: ~16K elements per block
+  int rows_per_blk = (16384 + C - 1) / C;
+  if (rows_per_blk > hw) rows_per_blk = hw;
+  const int nblk = (hw + rows_per_blk - 1) / rows_per_blk;
+  const size_t sh2 = (size_t)(2 * groups + 2 * C) * sizeof(float);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, batch), dim3(256), sh2, s, x0, x1, c0, c1, hw, groups, nchunk, eps, gamma,
+                     beta, silu, ws, rows_per_blk, y);
+  return check_launch("gn_apply");
+}
+
+int mvd_launch_layernorm(const bf16_t* x, int rows, int c, float eps, const float* gamma, const float* beta, bf16_t* y,
+                         hipStream_t s) {
+  if (!x || !y || !gamma || !beta || rows <= 0 || c <= 0 || (c % 8) || c > 64 * 8 * 4) {
+    mvd_set_error("layernorm: bad arguments rows=%d c=%d", rows, c);
+    return -1;
+  }
+  const int grid = (rows + 3) / 4;
+  if (c <= 512) hipLaunchKernelGGL(ln_kernel<1>, dim3(grid), dim3(256), 0, s, x, rows, c, eps, gamma, beta, y);
+  else if (c <= 1024) hipLaunchKernelGGL(ln_kernel<2>, dim3(grid), dim3(256), 0, s, x, rows, c, eps, gamma, beta, y);
+  else hipLaunchKernelGGL(ln_kernel<4>, dim3(grid), dim3(256), 0, s, x, rows, c, eps, gamma, beta, y);
+  return check_launch("layernorm");
+}
+
+int mvd_launch_refnorm(const bf16_t* x, int batch, int hw, int c, bf16_t* y, hipStream_t s) {
+  if (!x || !y || batch <= 0 || hw <= 0 || c <= 0 || (c % 8)) { mvd_set_error("refnorm: bad arguments"); return -1; }
+  hipLaunchKernelGGL(refnorm_kernel, dim3(hw), dim3(256), 0, s, x, batch, hw, c, y);
+  return check_launch("refnorm");
+}
+
+int mvd_launch_layernorm_f32(const float* x, int rows, int c, float eps, const float* gamma, const float* beta, int silu,
+                             float* y, hipStream_t s) {
+  if (!x || !y || !gamma || !beta || rows <= 0 || c <= 0) { mvd_set_error("layernorm_f32: bad arguments"); return -1; }
+  hipLaunchKernelGGL(ln_f32_kernel, dim3(rows), dim3(256), 0, s, x, c, eps, gamma, beta, silu, y);
+  return check_launch("layernorm_f32");
+}

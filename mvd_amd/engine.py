@@ -1,0 +1,171 @@
+"""Python handle on the C-ABI engine (include/mvd_hip.h).  torch is used only for device
+memory, streams and the one-time weight packing; every FLOP of the forward runs in
+libmvd_hip.so.  There is no CPU path: constructing an engine without a GPU raises."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib as L
+from .config import UNetConfig
+from .packing import pack_camera, pack_unet
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class MVDEngine:
+    def __init__(self, cfg: UNetConfig, cam_output_dim: int = 1024, cam_hidden_dim: int = 512,
+                 simple_cam_encoder: bool = False, cam_modulation_strength: float = 0.2, device="cuda:0"):
+        if not torch.cuda.is_available():
+            raise L.MvdError("MVDEngine needs a MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+        self.cfg = cfg
+        self.device = torch.device(device)
+        c = L.mvd_config_t()
+        c.in_channels, c.out_channels, c.num_levels = cfg.in_channels, cfg.out_channels, cfg.num_levels
+        for i in range(cfg.num_levels):
+            c.block_out_channels[i] = cfg.block_out_channels[i]
+            c.num_heads[i] = cfg.num_heads[i]
+        c.layers_per_block, c.cross_attention_dim = cfg.layers_per_block, cfg.cross_attention_dim
+        c.norm_num_groups, c.norm_eps = cfg.norm_num_groups, cfg.norm_eps
+        c.cam_output_dim, c.cam_hidden_dim = cam_output_dim, cam_hidden_dim
+        c.simple_cam_encoder, c.cam_modulation_strength = int(simple_cam_encoder), cam_modulation_strength
+        self.cam_output_dim = cam_output_dim
+        h = C.c_void_p()
+        L.call("mvd_engine_create", C.byref(c), C.byref(h))
+        self._h = h
+        self._weights: List[Dict[str, torch.Tensor]] = [{}, {}]   # keeps packed tensors alive
+        self._ws = None
+        self._rc = None
+        self._ws_key = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                L.lib().mvd_engine_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def _register(self, set_id: int, packed: Dict[str, torch.Tensor]):
+        for slot, t in packed.items():
+            assert t.is_cuda and t.is_contiguous()
+            dt = {torch.float32: 0, torch.bfloat16: 1}[t.dtype]
+            L.call("mvd_engine_set_weight", self._h, set_id, slot.encode(), _ptr(t), t.numel(), dt)
+        self._weights[set_id].update(packed)
+
+    def load_base(self, sd: Dict[str, torch.Tensor], adapter: bool, ref_scale: float):
+        """``sd``: diffusers keys of base_unet (+ ``...processor.*`` adapter keys when ``adapter``)."""
+        with torch.no_grad():
+            self._register(0, pack_unet(sd, self.cfg, self.device, adapter, ref_scale))
+
+    def load_camera(self, sd: Dict[str, torch.Tensor]):
+        with torch.no_grad():
+            self._register(0, pack_camera(sd, self.device))
+
+    def load_image_encoder(self, sd: Dict[str, torch.Tensor]):
+        with torch.no_grad():
+            self._register(1, pack_unet(sd, self.cfg, self.device, False))
+
+    def weight_bytes(self) -> int:
+        return sum(t.numel() * t.element_size() for d in self._weights for t in d.values())
+
+    # ------------------------------------------------------------------ workspace
+    def _ensure_workspace(self, batch, h, w, text_len, ref_batch, keep_features):
+        key = (batch, h, w, text_len, ref_batch, keep_features)
+        if self._ws_key == key:
+            return
+        ws = L.lib().mvd_engine_workspace_bytes(self._h, batch, h, w, text_len, ref_batch)
+        if ws < 0:
+            raise L.MvdError(f"workspace_bytes: {L.last_error()}")
+        rc = 0
+        if ref_batch > 0:
+            rc = L.lib().mvd_engine_refcache_bytes(self._h, ref_batch, h, w, int(keep_features))
+            if rc < 0:
+                raise L.MvdError(f"refcache_bytes: {L.last_error()}")
+        if self._ws is None or self._ws.numel() < ws:
+            self._ws = None
+            self._ws = torch.empty(ws, dtype=torch.uint8, device=self.device)
+        if rc and (self._rc is None or self._rc.numel() < rc):
+            self._rc = None
+            self._rc = torch.empty(rc, dtype=torch.uint8, device=self.device)
+        L.call("mvd_engine_bind_workspace", self._h, _ptr(self._ws), self._ws.numel(),
+               _ptr(self._rc) if rc else None, self._rc.numel() if rc else 0)
+        self._ws_key = key
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, sample: torch.Tensor, timesteps: torch.Tensor, text: torch.Tensor,
+                source_camera: Optional[torch.Tensor] = None, target_camera: Optional[torch.Tensor] = None,
+                fourier_proj: Optional[torch.Tensor] = None, source_latents: Optional[torch.Tensor] = None,
+                encoder_text: Optional[torch.Tensor] = None, reuse_ref: bool = False,
+                keep_features: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """All tensors fp32 contiguous on ``self.device``; returns fp32 NCHW."""
+        B, Cin, H, W = sample.shape
+        Lt = text.shape[1]
+        for t in (sample, timesteps, text, source_camera, target_camera, fourier_proj, source_latents, encoder_text):
+            if t is not None:
+                if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                    raise L.MvdError("engine.forward expects contiguous fp32 CUDA tensors")
+        if text.shape[0] != B or timesteps.shape != (B,):
+            raise L.MvdError(f"engine.forward: text batch {text.shape[0]} / timesteps {tuple(timesteps.shape)} vs batch {B}")
+        use_cam = target_camera is not None
+        use_img = source_latents is not None or reuse_ref
+        ref_batch = 0
+        if use_img:
+            ref_batch = source_latents.shape[0] if source_latents is not None else self._last_ref_batch
+            self._last_ref_batch = ref_batch
+        self._ensure_workspace(B, H, W, Lt, ref_batch, keep_features)
+        if out is None:
+            out = torch.empty(B, self.cfg.out_channels, H, W, dtype=torch.float32, device=self.device)
+        a = L.mvd_forward_args_t()
+        a.batch, a.height, a.width, a.text_len = B, H, W, Lt
+        a.sample, a.timesteps, a.text = sample.data_ptr(), timesteps.data_ptr(), text.data_ptr()
+        flags = 0
+        if use_cam:
+            if source_camera is None or fourier_proj is None:
+                raise L.MvdError("camera conditioning needs source_camera, target_camera and fourier_proj")
+            if source_camera.shape[0] != B or target_camera.shape[0] != B:
+                raise L.MvdError("camera batch must equal the sample batch")
+            a.source_camera, a.target_camera = source_camera.data_ptr(), target_camera.data_ptr()
+            a.cam_rows = source_camera.shape[1]
+            a.fourier_proj = fourier_proj.data_ptr()
+            flags |= L.MVD_USE_CAMERA
+        if use_img:
+            flags |= L.MVD_USE_IMAGE
+            if reuse_ref:
+                flags |= L.MVD_REUSE_REF
+            else:
+                if encoder_text is None or encoder_text.shape[0] != ref_batch:
+                    raise L.MvdError("image conditioning needs encoder_text with the reference batch")
+                a.source_latents, a.encoder_text = source_latents.data_ptr(), encoder_text.data_ptr()
+            if keep_features:
+                flags |= L.MVD_KEEP_FEATURES
+        a.ref_batch, a.flags = ref_batch, flags
+        a.out = out.data_ptr()
+        L.call("mvd_unet_forward", self._h, C.byref(a), _stream())
+        return out
+
+    # ------------------------------------------------------------------ introspection (parity tests)
+    def features(self) -> Dict[str, torch.Tensor]:
+        names = [t[1] for t in self.cfg.transformers()]
+        res = {}
+        for i, n in enumerate(names):
+            c, h, w = C.c_int(), C.c_int(), C.c_int()
+            L.call("mvd_engine_feature_shape", self._h, i, C.byref(c), C.byref(h), C.byref(w))
+            t = torch.empty(self._last_ref_batch, c.value, h.value, w.value, dtype=torch.float32, device=self.device)
+            L.call("mvd_engine_get_feature", self._h, i, _ptr(t), _stream())
+            res[n] = t
+        return res
+
+    def camera_embedding(self, batch: int) -> torch.Tensor:
+        t = torch.empty(batch, self.cam_output_dim, dtype=torch.float32, device=self.device)
+        L.call("mvd_engine_get_camera_embedding", self._h, _ptr(t), _stream())
+        return t

@@ -1,0 +1,138 @@
+"""Operator-level wrappers over the C ABI (the same kernels the engine schedules).
+
+Used by the parity tests and for bring-up; tensors are bf16/fp32 CUDA tensors, token-major
+(NHWC) activations.  No fallback: everything dispatches into libmvd_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+
+def _p(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "ops expect contiguous CUDA tensors"
+    return C.c_void_p(t.data_ptr())
+
+
+def _s():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _bf16(*ts):
+    for t in ts:
+        if t is not None:
+            assert t.dtype == torch.bfloat16, "expected bf16"
+
+
+def linear(a, w, bias=None, a2=None, rowvec=None, rows_per_batch=0, res=None, alpha=1.0, geglu=False,
+           out_f32=False, force_cfg=-1):
+    """out = alpha*( [a|a2] @ w.T + bias + rowvec[row // rows_per_batch] ) + res"""
+    _bf16(a, a2, w, res)
+    m, k1 = a.shape
+    k2 = a2.shape[1] if a2 is not None else 0
+    n = w.shape[0]
+    assert w.shape[1] == k1 + k2
+    on = n // 2 if geglu else n
+    out = torch.empty(m, on, device=a.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
+    L.call("mvd_op_linear", _p(a), _p(a2), k1, k2, _p(w), _p(bias), _p(rowvec),
+           rowvec.shape[1] if rowvec is not None else 0, rows_per_batch, _p(res), float(alpha), int(geglu),
+           _p(out), int(out_f32), m, n, force_cfg, _s())
+    return out
+
+
+def conv3x3(x, w_packed, bias=None, stride=1, upsample=False, rowvec=None, res=None, shortcut=None,
+            shortcut2=None, force_cfg=-1):
+    """x: (B,H,W,Cin) bf16; w_packed: (Cout, 9*Cin [+ Csc]) bf16 tap-major."""
+    _bf16(x, w_packed, res, shortcut, shortcut2)
+    B, H, W, Cin = x.shape
+    cout = w_packed.shape[0]
+    oh = H * 2 if upsample else (H + 1) // 2 if stride == 2 else H
+    ow = W * 2 if upsample else (W + 1) // 2 if stride == 2 else W
+    out = torch.empty(B, oh, ow, cout, device=x.device, dtype=torch.bfloat16)
+    c1 = shortcut.shape[-1] if shortcut is not None else 0
+    c2 = shortcut2.shape[-1] if shortcut2 is not None else 0
+    L.call("mvd_op_conv3x3", _p(x), B, H, W, Cin, stride, int(upsample), _p(w_packed), _p(bias), _p(rowvec),
+           rowvec.shape[1] if rowvec is not None else 0, _p(res), _p(shortcut), _p(shortcut2), c1, c2, _p(out), cout,
+           force_cfg, _s())
+    return out
+
+
+def attention(q, k, v, heads, scale=0.125):
+    """q: (B,Nq,heads*64) bf16, k/v: (B,Nk,heads*64); row strides may exceed heads*64 (views of fused buffers)."""
+    _bf16(q, k, v)
+    B, nq, _ = q.shape
+    nk = k.shape[1]
+    assert q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1
+    assert q.stride(0) == nq * q.stride(1) and k.stride(0) == nk * k.stride(1) and v.stride(0) == nk * v.stride(1)
+    out = torch.empty(B, nq, heads * 64, device=q.device, dtype=torch.bfloat16)
+    L.call("mvd_op_attention", C.c_void_p(q.data_ptr()), C.c_void_p(k.data_ptr()), C.c_void_p(v.data_ptr()), _p(out),
+           B, heads, nq, nk, q.stride(1), k.stride(1), v.stride(1), heads * 64, float(scale), _s())
+    return out
+
+
+def groupnorm(x, gamma, beta, groups=32, eps=1e-5, silu=False, x2=None):
+    """x: (B,HW,C0) bf16 [, x2: (B,HW,C1) concatenated on channels] -> (B,HW,C0+C1)"""
+    _bf16(x, x2)
+    B, hw, c0 = x.shape
+    c1 = x2.shape[2] if x2 is not None else 0
+    y = torch.empty(B, hw, c0 + c1, device=x.device, dtype=torch.bfloat16)
+    ws = torch.empty(B * 64 * groups * 2, device=x.device, dtype=torch.float32)
+    L.call("mvd_op_groupnorm", _p(x), _p(x2), c0, c1, B, hw, groups, float(eps), _p(gamma), _p(beta), int(silu), _p(y),
+           _p(ws), _s())
+    return y
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    _bf16(x)
+    rows, c = x.shape
+    y = torch.empty_like(x)
+    L.call("mvd_op_layernorm", _p(x), rows, c, float(eps), _p(gamma), _p(beta), _p(y), _s())
+    return y
+
+
+def refnorm(x):
+    """(B,HW,C) bf16 -> per-pixel normalisation over (batch, channel) (attention.py:95-103 of the reference)."""
+    _bf16(x)
+    B, hw, c = x.shape
+    y = torch.empty_like(x)
+    L.call("mvd_op_refnorm", _p(x), B, hw, c, _p(y), _s())
+    return y
+
+
+def film(x, scale, shift):
+    _bf16(x)
+    B, hw, c = x.shape
+    y = torch.empty_like(x)
+    L.call("mvd_op_film", _p(x), B, hw, c, _p(scale), _p(shift), _p(y), _s())
+    return y
+
+
+def conv_in(x, w, bias):
+    """x (B,H,W,Cin) bf16, w (Cout,3,3,Cin) fp32 -> (B,H,W,Cout) bf16"""
+    B, H, W, cin = x.shape
+    cout = w.shape[0]
+    y = torch.empty(B, H, W, cout, device=x.device, dtype=torch.bfloat16)
+    L.call("mvd_op_conv_in", _p(x), B, H, W, cin, _p(w), _p(bias), cout, _p(y), _s())
+    return y
+
+
+def conv_out(x, w, bias):
+    """x (B,H,W,C) bf16, w (Cout, 9*C) bf16 -> (B,Cout,H,W) fp32"""
+    B, H, W, c = x.shape
+    cout = w.shape[0]
+    y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32)
+    L.call("mvd_op_conv_out", _p(x), B, H, W, c, _p(w), _p(bias), cout, _p(y), _s())
+    return y
+
+
+def nchw_to_nhwc(x, scale=None, shift=None):
+    B, c, H, W = x.shape
+    y = torch.empty(B, H, W, c, device=x.device, dtype=torch.bfloat16)
+    L.call("mvd_op_nchw_to_nhwc", _p(x), B, c, H * W, _p(scale), _p(shift), _p(y), _s())
+    return y

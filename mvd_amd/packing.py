@@ -1,0 +1,127 @@
+"""State-dict (reference / diffusers key names) -> packed device weights for libmvd_hip.so.
+
+One-time host work (torch is used as plumbing for the permutes / casts).  Slot layouts
+(documented in DESIGN.md "Weight slots"):
+
+  conv          [Cout][ky][kx][Cin] bf16  (K = 9*Cin contiguous, tap-major)
+  resnet conv2  conv2 | conv_shortcut(1x1) concatenated along K, biases summed
+  attn1.qkv     [to_q; to_k; to_v; (to_q_ref)]            rows concatenated
+  attn1.out     [to_out.0 | ref_scale * to_out_ref.0]     K concatenated, bias = b + ref_scale*b_ref
+  attn2.q       [to_q; (to_q_ref)]     attn2.kv [to_k; to_v]
+  ref_kv        [to_k_ref(self); to_v_ref(self); to_k_ref(cross); to_v_ref(cross)]
+  ff1           GEGLU rows interleaved in blocks of 16: (16 value rows, 16 gate rows)
+  temb_proj     every resnet's time_emb_proj stacked in module order (one GEMM per forward)
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+
+from .config import UNetConfig
+
+
+def _bf(t: torch.Tensor, device) -> torch.Tensor:
+    return t.detach().to(device=device, dtype=torch.float32).to(torch.bfloat16).contiguous()
+
+
+def _f32(t: torch.Tensor, device) -> torch.Tensor:
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+def _conv_w(w: torch.Tensor) -> torch.Tensor:
+    co, ci, kh, kw = w.shape
+    return w.detach().float().permute(0, 2, 3, 1).reshape(co, kh * kw * ci)
+
+
+def _geglu_rows(w: torch.Tensor) -> torch.Tensor:
+    """[8C, ...] -> rows re-ordered so each block of 32 = 16 value rows then the 16 matching gate rows."""
+    half = w.shape[0] // 2
+    val, gate = w[:half], w[half:]
+    rest = w.shape[1:]
+    v = val.reshape(half // 16, 1, 16, *rest)
+    g = gate.reshape(half // 16, 1, 16, *rest)
+    return torch.cat([v, g], dim=1).reshape(w.shape)
+
+
+def pack_unet(sd: Dict[str, torch.Tensor], cfg: UNetConfig, device, adapter: bool, ref_scale: float = 0.0) -> Dict[str, torch.Tensor]:
+    """``sd`` holds diffusers keys (no wrapper prefix) and, when ``adapter``, the ``...processor.*`` keys."""
+    out: Dict[str, torch.Tensor] = {}
+    out["conv_in.w"] = _f32(_conv_w(sd["conv_in.weight"]), device)
+    out["conv_in.b"] = _f32(sd["conv_in.bias"], device)
+    out["time.l1.w"] = _bf(sd["time_embedding.linear_1.weight"], device)
+    out["time.l1.b"] = _f32(sd["time_embedding.linear_1.bias"], device)
+    out["time.l2.w"] = _bf(sd["time_embedding.linear_2.weight"], device)
+    out["time.l2.b"] = _f32(sd["time_embedding.linear_2.bias"], device)
+    tw, tb = [], []
+    for key, cin, cout in cfg.resnets():
+        out[f"{key}.norm1.g"] = _f32(sd[f"{key}.norm1.weight"], device)
+        out[f"{key}.norm1.b"] = _f32(sd[f"{key}.norm1.bias"], device)
+        out[f"{key}.conv1.w"] = _bf(_conv_w(sd[f"{key}.conv1.weight"]), device)
+        out[f"{key}.conv1.b"] = _f32(sd[f"{key}.conv1.bias"], device)
+        out[f"{key}.norm2.g"] = _f32(sd[f"{key}.norm2.weight"], device)
+        out[f"{key}.norm2.b"] = _f32(sd[f"{key}.norm2.bias"], device)
+        w2 = _conv_w(sd[f"{key}.conv2.weight"])
+        b2 = sd[f"{key}.conv2.bias"].detach().float()
+        if cin != cout:
+            w2 = torch.cat([w2, sd[f"{key}.conv_shortcut.weight"].detach().float().reshape(cout, cin)], dim=1)
+            b2 = b2 + sd[f"{key}.conv_shortcut.bias"].detach().float()
+        out[f"{key}.conv2.w"] = _bf(w2, device)
+        out[f"{key}.conv2.b"] = _f32(b2, device)
+        tw.append(sd[f"{key}.time_emb_proj.weight"].detach().float())
+        tb.append(sd[f"{key}.time_emb_proj.bias"].detach().float())
+    out["temb_proj.w"] = _bf(torch.cat(tw, 0), device)
+    out["temb_proj.b"] = _f32(torch.cat(tb, 0), device)
+
+    for key, _feat, C, _heads in cfg.transformers():
+        b = f"{key}.transformer_blocks.0"
+        out[f"{key}.norm.g"] = _f32(sd[f"{key}.norm.weight"], device)
+        out[f"{key}.norm.b"] = _f32(sd[f"{key}.norm.bias"], device)
+        out[f"{key}.proj_in.w"] = _bf(sd[f"{key}.proj_in.weight"], device)
+        out[f"{key}.proj_in.b"] = _f32(sd[f"{key}.proj_in.bias"], device)
+        out[f"{key}.proj_out.w"] = _bf(sd[f"{key}.proj_out.weight"], device)
+        out[f"{key}.proj_out.b"] = _f32(sd[f"{key}.proj_out.bias"], device)
+        for i in (1, 2, 3):
+            out[f"{key}.ln{i}.g"] = _f32(sd[f"{b}.norm{i}.weight"], device)
+            out[f"{key}.ln{i}.b"] = _f32(sd[f"{b}.norm{i}.bias"], device)
+        f = lambda k: sd[k].detach().float()  # noqa: E731
+        qkv = [f(f"{b}.attn1.to_q.weight"), f(f"{b}.attn1.to_k.weight"), f(f"{b}.attn1.to_v.weight")]
+        q2 = [f(f"{b}.attn2.to_q.weight")]
+        for a in ("attn1", "attn2"):
+            wo, bo = f(f"{b}.{a}.to_out.0.weight"), f(f"{b}.{a}.to_out.0.bias")
+            if adapter:
+                pr = f"{b}.{a}.processor"
+                wo = torch.cat([wo, ref_scale * f(f"{pr}.to_out_ref.0.weight")], dim=1)
+                bo = bo + ref_scale * f(f"{pr}.to_out_ref.0.bias")
+            out[f"{key}.{a}.out.w"] = _bf(wo, device)
+            out[f"{key}.{a}.out.b"] = _f32(bo, device)
+        if adapter:
+            p1, p2 = f"{b}.attn1.processor", f"{b}.attn2.processor"
+            qkv.append(f(f"{p1}.to_q_ref.weight"))
+            q2.append(f(f"{p2}.to_q_ref.weight"))
+            out[f"{key}.ref_kv.w"] = _bf(torch.cat([f(f"{p1}.to_k_ref.weight"), f(f"{p1}.to_v_ref.weight"),
+                                                    f(f"{p2}.to_k_ref.weight"), f(f"{p2}.to_v_ref.weight")], 0), device)
+        out[f"{key}.attn1.qkv.w"] = _bf(torch.cat(qkv, 0), device)
+        out[f"{key}.attn2.q.w"] = _bf(torch.cat(q2, 0), device)
+        out[f"{key}.attn2.kv.w"] = _bf(torch.cat([f(f"{b}.attn2.to_k.weight"), f(f"{b}.attn2.to_v.weight")], 0), device)
+        out[f"{key}.ff1.w"] = _bf(_geglu_rows(f(f"{b}.ff.net.0.proj.weight")), device)
+        out[f"{key}.ff1.b"] = _f32(_geglu_rows(f(f"{b}.ff.net.0.proj.bias")), device)
+        out[f"{key}.ff2.w"] = _bf(sd[f"{b}.ff.net.2.weight"], device)
+        out[f"{key}.ff2.b"] = _f32(sd[f"{b}.ff.net.2.bias"], device)
+
+    n = cfg.num_levels
+    for i in range(n - 1):
+        out[f"down_blocks.{i}.down.w"] = _bf(_conv_w(sd[f"down_blocks.{i}.downsamplers.0.conv.weight"]), device)
+        out[f"down_blocks.{i}.down.b"] = _f32(sd[f"down_blocks.{i}.downsamplers.0.conv.bias"], device)
+        out[f"up_blocks.{i}.up.w"] = _bf(_conv_w(sd[f"up_blocks.{i}.upsamplers.0.conv.weight"]), device)
+        out[f"up_blocks.{i}.up.b"] = _f32(sd[f"up_blocks.{i}.upsamplers.0.conv.bias"], device)
+    out["conv_norm_out.g"] = _f32(sd["conv_norm_out.weight"], device)
+    out["conv_norm_out.b"] = _f32(sd["conv_norm_out.bias"], device)
+    out["conv_out.w"] = _bf(_conv_w(sd["conv_out.weight"]), device)
+    out["conv_out.b"] = _f32(sd["conv_out.bias"], device)
+    return out
+
+
+def pack_camera(sd: Dict[str, torch.Tensor], device) -> Dict[str, torch.Tensor]:
+    """Camera encoder stays fp32 (Q9): slots are the reference keys prefixed with ``cam.``."""
+    return {f"cam.{k}": _f32(v, device) for k, v in sd.items()}

@@ -1,0 +1,230 @@
+"""Operator-level parity: every HIP kernel vs a plain PyTorch fp32 reference of the same op,
+on bf16-rounded inputs (so the only differences are accumulation order and the final bf16
+rounding).  Tolerance: |err| <= 2^-7 * max|ref| (bf16 has 8 significant bits) unless stated."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mvd_amd import ops as O
+    return O
+
+
+def rnd(*shape, scale=1.0, seed=0, dtype=torch.bfloat16):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+def close(got, want, tol=2 ** -7, what=""):
+    got = got.float().cpu()
+    want = want.float()
+    assert got.shape == want.shape, (got.shape, want.shape)
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    err = (got - want).abs().max().item()
+    ref = want.abs().max().item()
+    rel_l2 = ((got - want).norm() / want.norm().clamp_min(1e-12)).item()
+    assert err <= tol * ref + 1e-6, f"{what}: max-abs {err:.4g} vs ref max {ref:.4g} (rel-L2 {rel_l2:.3g})"
+    return rel_l2
+
+
+# ------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("m,n,k", [(300, 640, 320), (1024, 1280, 192), (77, 640, 1024), (5, 1920, 64)])
+def test_linear_configs(ops, cfg, m, n, k):
+    tiles = {0: 160, 1: 128, 2: 160, 3: 128, 4: 64, 5: 64}
+    if cfg >= 0 and n % tiles[cfg]:
+        pytest.skip("N not divisible by this tile")
+    a, w = rnd(m, k, seed=1), rnd(n, k, scale=1 / math.sqrt(k), seed=2)
+    bias = rnd(n, seed=3, dtype=torch.float32)
+    want = a.float() @ w.float().T + bias
+    got = ops.linear(a.cuda(), w.cuda(), bias.cuda(), force_cfg=cfg)
+    close(got, want, what=f"linear cfg{cfg}")
+
+
+def test_linear_epilogues(ops):
+    m, n, k1, k2, rpb = 384, 320, 128, 192, 96
+    a, a2 = rnd(m, k1, seed=1), rnd(m, k2, seed=2)
+    w = rnd(n, k1 + k2, scale=1 / math.sqrt(k1 + k2), seed=3)
+    bias = rnd(n, seed=4, dtype=torch.float32)
+    rowvec = rnd(m // rpb, n, seed=5, dtype=torch.float32)
+    res = rnd(m, n, seed=6)
+    want = 0.3 * (torch.cat([a, a2], 1).float() @ w.float().T + bias + rowvec.repeat_interleave(rpb, 0)) + res.float()
+    got = ops.linear(a.cuda(), w.cuda(), bias.cuda(), a2=a2.cuda(), rowvec=rowvec.cuda(), rows_per_batch=rpb,
+                     res=res.cuda(), alpha=0.3)
+    close(got, want, what="linear dual-source+rowvec+res+alpha")
+    got32 = ops.linear(a.cuda(), w[:, :k1].contiguous().cuda(), bias.cuda(), out_f32=True)
+    close(got32, a.float() @ w[:, :k1].float().T + bias, tol=1e-4, what="linear fp32 out")
+
+
+@pytest.mark.parametrize("cfg", [-1, 1, 3, 4, 5])
+def test_linear_geglu(ops, cfg):
+    from mvd_amd.packing import _geglu_rows
+    m, c = 200, 128
+    a = rnd(m, c, seed=1)
+    w = rnd(8 * c, c, scale=1 / math.sqrt(c), seed=2)
+    bias = rnd(8 * c, seed=3, dtype=torch.float32)
+    f = a.float() @ w.float().T + bias
+    val, gate = f.chunk(2, -1)
+    want = val * F.gelu(gate)
+    got = ops.linear(a.cuda(), _geglu_rows(w).contiguous().cuda(), _geglu_rows(bias).contiguous().cuda(), geglu=True,
+                     force_cfg=cfg)
+    close(got, want, what=f"geglu cfg{cfg}")
+
+
+# ------------------------------------------------------------------------------- conv
+def _pack(w):
+    co, ci = w.shape[:2]
+    return w.float().permute(0, 2, 3, 1).reshape(co, -1).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("stride,ups", [(1, False), (2, False), (1, True)])
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 16, 16, 64, 128), (1, 8, 12, 192, 64), (3, 6, 6, 128, 320)])
+def test_conv3x3(ops, stride, ups, B, H, W, cin, cout):
+    x = rnd(B, cin, H, W, seed=1)
+    w = rnd(cout, cin, 3, 3, scale=1 / math.sqrt(9 * cin), seed=2)
+    bias = rnd(cout, seed=3, dtype=torch.float32)
+    xin = x.float()
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    want = F.conv2d(xin, w.float(), bias, stride=stride, padding=1).permute(0, 2, 3, 1)
+    got = ops.conv3x3(x.permute(0, 2, 3, 1).contiguous().cuda(), _pack(w).cuda(), bias.cuda(), stride=stride, upsample=ups)
+    close(got, want, what=f"conv3x3 s{stride} ups{ups}")
+
+
+@pytest.mark.parametrize("cfg", [-1, 0, 2, 4, 5])
+def test_conv3x3_resnet_fusions(ops, cfg):
+    """conv1 (+time-embedding row vector) and conv2 (+1x1 shortcut over a 2-source concat / + residual)."""
+    B, H, W, c0, c1, cout = 2, 8, 8, 128, 64, 320
+    x0, x1 = rnd(B, c0, H, W, seed=1), rnd(B, c1, H, W, seed=2)
+    h = rnd(B, cout, H, W, seed=3)
+    w2 = rnd(cout, cout, 3, 3, scale=1 / math.sqrt(9 * cout), seed=4)
+    wsc = rnd(cout, c0 + c1, 1, 1, scale=1 / math.sqrt(c0 + c1), seed=5)
+    bias = rnd(cout, seed=6, dtype=torch.float32)
+    temb = rnd(B, cout, seed=7, dtype=torch.float32)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()  # noqa: E731
+    want = F.conv2d(h.float(), w2.float(), bias, padding=1) + F.conv2d(torch.cat([x0, x1], 1).float(), wsc.float())
+    wp = torch.cat([_pack(w2), wsc.reshape(cout, c0 + c1)], 1).contiguous()
+    got = ops.conv3x3(nhwc(h), wp.cuda(), bias.cuda(), shortcut=nhwc(x0), shortcut2=nhwc(x1), force_cfg=cfg)
+    close(got, want.permute(0, 2, 3, 1), what="conv2+shortcut")
+    want = F.conv2d(h.float(), w2.float(), bias, padding=1) + temb[:, :, None, None] + h.float()
+    got = ops.conv3x3(nhwc(h), _pack(w2).cuda(), bias.cuda(), rowvec=temb.cuda(), res=nhwc(h), force_cfg=cfg)
+    close(got, want.permute(0, 2, 3, 1), what="conv+temb+residual")
+
+
+def test_conv_in_out(ops):
+    B, H, W, c = 2, 16, 12, 64
+    x = rnd(B, 4, H, W, seed=1)
+    w = rnd(c, 4, 3, 3, scale=1 / 6, seed=2, dtype=torch.float32)
+    b = rnd(c, seed=3, dtype=torch.float32)
+    want = F.conv2d(x.float(), w, b, padding=1).permute(0, 2, 3, 1)
+    got = ops.conv_in(x.permute(0, 2, 3, 1).contiguous().cuda(), w.permute(0, 2, 3, 1).contiguous().cuda(), b.cuda())
+    close(got, want, what="conv_in")
+    y = rnd(B, c, H, W, seed=4)
+    w2 = rnd(4, c, 3, 3, scale=1 / math.sqrt(9 * c), seed=5)
+    b2 = rnd(4, seed=6, dtype=torch.float32)
+    want = F.conv2d(y.float(), w2.float(), b2, padding=1)
+    got = ops.conv_out(y.permute(0, 2, 3, 1).contiguous().cuda(), _pack(w2).cuda(), b2.cuda())
+    close(got, want, tol=1e-4, what="conv_out")
+
+
+# ------------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("B,heads,nq,nk", [
+    (2, 5, 256, 256),      # self-attention, multiple of every tile
+    (1, 2, 64, 77),        # text cross-attention: ragged key tile
+    (3, 1, 16, 16),        # fewer queries than one wave tile
+    (2, 2, 144, 144),      # 768^2-style ragged query count
+    (1, 20, 64, 32),       # Q4: reference tokens re-chunked (nk = N/2)
+    (1, 5, 1024, 1024),    # multi-tile, 8-wave path
+    (1, 1, 4, 4),
+])
+def test_attention(ops, B, heads, nq, nk):
+    C = heads * 64
+    q, k, v = rnd(B, nq, C, seed=1), rnd(B, nk, C, seed=2), rnd(B, nk, C, seed=3)
+    qh = q.float().view(B, nq, heads, 64).transpose(1, 2)
+    kh = k.float().view(B, nk, heads, 64).transpose(1, 2)
+    vh = v.float().view(B, nk, heads, 64).transpose(1, 2)
+    want = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, nq, C)
+    got = ops.attention(q.cuda(), k.cuda(), v.cuda(), heads)
+    close(got, want, tol=2 ** -6, what=f"attention {B}x{heads}x{nq}x{nk}")
+
+
+def test_attention_strided_views_and_spike(ops):
+    """Fused-QKV strides, plus a forced online-softmax rescale (one key spikes late in the sequence)."""
+    B, heads, n = 2, 2, 320
+    C = heads * 64
+    qkv = rnd(B, n, 3 * C, seed=5)
+    qkv[:, 300, C:2 * C] *= 6.0          # late key with a huge score -> running max jumps at the last tile
+    g = qkv.cuda()
+    q, k, v = g[:, :, :C], g[:, :, C:2 * C], g[:, :, 2 * C:]
+    got = ops.attention(q, k, v, heads)
+    f = qkv.float()
+    sp = lambda t: t.reshape(B, n, heads, 64).transpose(1, 2)  # noqa: E731
+    want = F.scaled_dot_product_attention(sp(f[:, :, :C]), sp(f[:, :, C:2 * C]), sp(f[:, :, 2 * C:]))
+    close(got, want.transpose(1, 2).reshape(B, n, C), tol=2 ** -6, what="attention strided+spike")
+
+
+# ------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("B,hw,c0,c1", [(2, 256, 320, 0), (1, 64, 1280, 640), (3, 16, 64, 64), (2, 4096, 64, 0), (1, 4, 1280, 1280)])
+@pytest.mark.parametrize("silu", [False, True])
+def test_groupnorm(ops, B, hw, c0, c1, silu):
+    x = rnd(B, hw, c0, seed=1, scale=2.0) + 0.5
+    x = x.to(torch.bfloat16)
+    x2 = rnd(B, hw, c1, seed=2) if c1 else None
+    C = c0 + c1
+    g = 1 + 0.1 * rnd(C, seed=3, dtype=torch.float32)
+    b = 0.1 * rnd(C, seed=4, dtype=torch.float32)
+    full = torch.cat([x, x2], 2) if c1 else x
+    want = F.group_norm(full.float().permute(0, 2, 1), 32, g, b, 1e-5).permute(0, 2, 1)
+    if silu:
+        want = F.silu(want)
+    got = ops.groupnorm(x.cuda(), g.cuda(), b.cuda(), silu=silu, x2=x2.cuda() if c1 else None)
+    close(got, want, what="groupnorm")
+
+
+@pytest.mark.parametrize("rows,c", [(100, 320), (7, 640), (33, 1280), (5, 64)])
+def test_layernorm(ops, rows, c):
+    x = rnd(rows, c, seed=1, scale=3.0)
+    g = 1 + 0.1 * rnd(c, seed=2, dtype=torch.float32)
+    b = 0.1 * rnd(c, seed=3, dtype=torch.float32)
+    want = F.layer_norm(x.float(), (c,), g, b, 1e-5)
+    close(ops.layernorm(x.cuda(), g.cuda(), b.cuda()), want, what="layernorm")
+
+
+@pytest.mark.parametrize("B,hw,c", [(1, 64, 320), (4, 16, 128), (32, 4, 64)])
+def test_refnorm(ops, B, hw, c):
+    """Q2 of SURVEY.md: per-pixel statistics over (batch, channel), unbiased std, clamp, x0.5."""
+    x = (rnd(B, hw, c, seed=1, scale=1.7) + 0.3).to(torch.bfloat16)
+    nchw = x.float().permute(0, 2, 1).reshape(B, c, hw, 1)
+    r = nchw - nchw.mean(dim=(0, 1), keepdim=True)
+    want = (r / torch.clamp(r.std(dim=(0, 1), keepdim=True), min=1e-6) * 0.5).reshape(B, c, hw).permute(0, 2, 1)
+    close(ops.refnorm(x.cuda()), want, what="refnorm")
+
+
+def test_film_and_layout(ops):
+    B, hw, c = 3, 32, 128
+    x = rnd(B, hw, c, seed=1)
+    s, t = rnd(B, c, seed=2, dtype=torch.float32), rnd(B, c, seed=3, dtype=torch.float32)
+    close(ops.film(x.cuda(), s.cuda(), t.cuda()), x.float() * s[:, None] + t[:, None], what="film")
+    xi = rnd(2, 4, 8, 8, seed=4, dtype=torch.float32)
+    s4, t4 = rnd(2, 4, seed=5, dtype=torch.float32), rnd(2, 4, seed=6, dtype=torch.float32)
+    want = (xi * s4[:, :, None, None] + t4[:, :, None, None]).permute(0, 2, 3, 1)
+    close(ops.nchw_to_nhwc(xi.cuda(), s4.cuda(), t4.cuda()), want, what="nchw_to_nhwc+film")
+
+
+def test_bad_shapes_are_rejected(ops):
+    """The host must refuse shapes the kernels do not support (never launch a faulting kernel)."""
+    from mvd_amd._lib import MvdError
+    a, w = rnd(8, 96).cuda(), rnd(64, 96).cuda()         # K not a multiple of 64
+    with pytest.raises(MvdError):
+        ops.linear(a, w)
+    a, w = rnd(8, 64).cuda(), rnd(96, 64).cuda()         # N not a multiple of 64
+    with pytest.raises(MvdError):
+        ops.linear(a, w)
