@@ -100,6 +100,13 @@ int mvd_unet_forward(mvd_engine_t* e, const mvd_forward_args_t* args, void* stre
 int mvd_engine_num_features(mvd_engine_t* e);
 int mvd_engine_feature_shape(mvd_engine_t* e, int idx, int* channels, int* height, int* width);
 int mvd_engine_get_feature(mvd_engine_t* e, int idx, float* out_nchw, void* stream);
+/* CameraEncoder.encode_cameras (camera_encoder.py:160-176): cameras [batch][cam_rows][4] -> out_emb [batch][cam_output_dim] */
+int mvd_engine_encode_cameras(mvd_engine_t* e, const float* source_camera, const float* target_camera, int cam_rows,
+                              int batch, const float* fourier_proj, float* out_emb, void* stream);
+/* CameraEncoder.apply_modulation_to_tensor (camera_encoder.py:207-255) on x [batch][channels][hw] fp32.
+ * Returns 1 (and writes nothing) when `name` is not a modulator -- the reference's silent identity (Q3). */
+int mvd_engine_apply_modulation(mvd_engine_t* e, const char* name, const float* emb, int batch, const float* x_nchw,
+                                int channels, int hw, float* out_nchw, void* stream);
 /* Camera embedding of the last forward ([batch][cam_output_dim] fp32), for parity tests. */
 int mvd_engine_get_camera_embedding(mvd_engine_t* e, float* out, void* stream);
 

@@ -51,6 +51,8 @@ _SIGS = {
     "mvd_engine_num_features": (C.c_int, [C.c_void_p]),
     "mvd_engine_feature_shape": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mvd_engine_get_feature": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "mvd_engine_encode_cameras": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mvd_engine_apply_modulation": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mvd_engine_get_camera_embedding": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mvd_op_linear": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                 C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -103,8 +103,9 @@ struct Ctx {
 
   // dense linear: out[M][N] = alpha*(A.W^T + bias) + res
   int linear(const bf16_t* a, const bf16_t* a2, int k1, int k2, int M, const bf16_t* w, const float* bias, int N,
-             const bf16_t* res, int ldres, void* out, int ldo, bool geglu = false, bool out_f32 = false) {
+             const bf16_t* res, int ldres, void* out, int ldo, bool geglu = false, bool out_f32 = false, int ldw = 0) {
     MvdGemmArgs g; memset(&g, 0, sizeof(g));
+    g.ldw = ldw ? ldw : k1 + k2;
     g.seg[0].p0 = a; g.seg[0].p1 = a2; g.seg[0].c0 = k1; g.seg[0].c1 = k2; g.seg[0].mode = MVD_A_DENSE; g.seg[0].ksize = k1 + k2;
     g.nseg = 1; g.W = w; g.M = M; g.N = N; g.Ktot = k1 + k2; g.rows_per_batch = M; g.outH = 1; g.outW = M;
     g.bias = bias; g.res = res; g.ldres = ldres; g.alpha = 1.f; g.geglu = geglu; g.out = out; g.ldo = ldo; g.out_f32 = out_f32;
@@ -121,7 +122,7 @@ struct Ctx {
       g.seg[1].p0 = sc0; g.seg[1].p1 = sc1; g.seg[1].c0 = scc0; g.seg[1].c1 = scc1; g.seg[1].mode = MVD_A_DENSE;
       g.seg[1].ksize = scc0 + scc1; g.nseg = 2; g.Ktot += scc0 + scc1;
     }
-    g.W = w; g.M = out.rows(); g.N = out.C; g.rows_per_batch = out.hw(); g.outH = out.H; g.outW = out.W;
+    g.W = w; g.ldw = g.Ktot; g.M = out.rows(); g.N = out.C; g.rows_per_batch = out.hw(); g.outH = out.H; g.outW = out.W;
     g.bias = bias; g.rowvec = rowvec; g.ld_rowvec = ld_rowvec; g.res = res; g.ldres = out.C; g.alpha = 1.f;
     g.out = out.p; g.ldo = out.C;
     return gemm(g);
@@ -229,6 +230,12 @@ struct UNetPass {
     const int xd = cfg.cross_attention_dim;
     const FeatureInfo& fi = c.e->feats[feat_idx];
     const bool ad = o.adapter;
+    // set 0 may carry the adapter rows/columns even when this pass does not use them (no image conditioning):
+    // q/k/v rows are a prefix of the fused matrix, the out-projection is addressed with its packed row stride.
+    const bool packed = c.set == 0 && (c.dry || c.has(key + ".ref_kv.w", 0));
+    if (ad && !packed) { mvd_set_error("adapter requested but no adapter weights registered for %s", key.c_str()); return -14; }
+    const int ld_out = packed ? 2 * C : C;
+    const char* bias_slot = (packed && !ad) ? ".out.b0" : ".out.b";
     const size_t mark = c.e->tmp.off;
     bf16_t* n0 = c.talloc<bf16_t>((size_t)M * C);
     CHECK(c.groupnorm(x.p, nullptr, C, 0, B_, hw, 1e-6f, c.WF(key + ".norm.g", C), c.WF(key + ".norm.b", C), 0, n0));
@@ -248,14 +255,15 @@ struct UNetPass {
       const int nq = ad ? 4 * C : 3 * C;
       bf16_t* qkv = c.talloc<bf16_t>((size_t)M * nq);
       CHECK(c.layernorm(h, M, C, c.WF(key + ".ln1.g", C), c.WF(key + ".ln1.b", C), ln));
-      CHECK(c.linear(ln, nullptr, C, 0, M, c.WB(key + ".attn1.qkv.w", (int64_t)nq * C), nullptr, nq, nullptr, 0, qkv, nq));
+      CHECK(c.linear(ln, nullptr, C, 0, M, c.WB(key + ".attn1.qkv.w", (int64_t)(packed ? 4 : 3) * C * C), nullptr, nq, nullptr, 0, qkv, nq));
       MvdAttnArgs a; memset(&a, 0, sizeof(a));
       a.batch = B_; a.heads = heads; a.scale = scale; a.nprob = ad ? 2 : 1;
       a.p[0] = {qkv, qkv + C, qkv + 2 * C, o_self, nq, nq, nq, C, (int64_t)hw * nq, (int64_t)hw * nq, (int64_t)hw * nq, (int64_t)hw * C, hw, hw};
       if (ad) a.p[1] = {qkv + 3 * C, rkv, rkv + C, o_ref, nq, 4 * C, 4 * C, C, (int64_t)hw * nq, (int64_t)ref_nk * 4 * C, (int64_t)ref_nk * 4 * C, (int64_t)hw * C, hw, ref_nk};
       CHECK(c.attention(a));
       const int kout = ad ? 2 * C : C;
-      CHECK(c.linear(o_self, o_ref, C, ad ? C : 0, M, c.WB(key + ".attn1.out.w", (int64_t)C * kout), c.WF(key + ".attn1.out.b", C), C, h, C, h, C));
+      (void)kout;
+      CHECK(c.linear(o_self, o_ref, C, ad ? C : 0, M, c.WB(key + ".attn1.out.w", (int64_t)C * ld_out), c.WF(key + ".attn1" + bias_slot, C), C, h, C, h, C, false, false, ld_out));
     }
     // ---- attn2 (text cross) + adapter branch "<feature>_cross"
     {
@@ -263,7 +271,7 @@ struct UNetPass {
       bf16_t* q2 = c.talloc<bf16_t>((size_t)M * nq);
       bf16_t* kv2 = c.talloc<bf16_t>((size_t)B_ * L * 2 * C);
       CHECK(c.layernorm(h, M, C, c.WF(key + ".ln2.g", C), c.WF(key + ".ln2.b", C), ln));
-      CHECK(c.linear(ln, nullptr, C, 0, M, c.WB(key + ".attn2.q.w", (int64_t)nq * C), nullptr, nq, nullptr, 0, q2, nq));
+      CHECK(c.linear(ln, nullptr, C, 0, M, c.WB(key + ".attn2.q.w", (int64_t)(packed ? 2 : 1) * C * C), nullptr, nq, nullptr, 0, q2, nq));
       CHECK(c.linear(text, nullptr, xd, 0, B_ * L, c.WB(key + ".attn2.kv.w", (int64_t)2 * C * xd), nullptr, 2 * C, nullptr, 0, kv2, 2 * C));
       MvdAttnArgs a; memset(&a, 0, sizeof(a));
       a.batch = B_; a.heads = heads; a.scale = scale; a.nprob = ad ? 2 : 1;
@@ -271,7 +279,8 @@ struct UNetPass {
       if (ad) a.p[1] = {q2 + C, rkv + 2 * C, rkv + 3 * C, o_ref, nq, 4 * C, 4 * C, C, (int64_t)hw * nq, (int64_t)ref_nk * 4 * C, (int64_t)ref_nk * 4 * C, (int64_t)hw * C, hw, ref_nk};
       CHECK(c.attention(a));
       const int kout = ad ? 2 * C : C;
-      CHECK(c.linear(o_self, o_ref, C, ad ? C : 0, M, c.WB(key + ".attn2.out.w", (int64_t)C * kout), c.WF(key + ".attn2.out.b", C), C, h, C, h, C));
+      (void)kout;
+      CHECK(c.linear(o_self, o_ref, C, ad ? C : 0, M, c.WB(key + ".attn2.out.w", (int64_t)C * ld_out), c.WF(key + ".attn2" + bias_slot, C), C, h, C, h, C, false, false, ld_out));
     }
     // ---- GEGLU feed-forward
     {
@@ -410,10 +419,10 @@ int time_path(Ctx& c, const float* timesteps, int B, const float** tproj_out) {
   return 0;
 }
 
-// camera encoder (fp32, Q9) + FiLM parameters of every modulator
-int camera_path(Ctx& c, const mvd_forward_args_t& a, std::unordered_map<std::string, std::pair<float*, float*>>& ss) {
+// camera encoder (fp32, Q9): cameras -> embedding [B][D]   (camera_encoder.py:160-196)
+int camera_embed(Ctx& c, const float* src, const float* tgt, int cam_rows, const float* proj, int B, float* emb) {
   const mvd_config_t& cfg = c.e->cfg;
-  const int B = a.batch, D = cfg.cam_output_dim, Hd = cfg.cam_hidden_dim;
+  const int D = cfg.cam_output_dim, Hd = cfg.cam_hidden_dim;
   const int nfreq = (D / 2) / 3, encd = 6 * nfreq;
   const bool simple = cfg.simple_cam_encoder != 0;
   float* rflat = c.talloc<float>((size_t)B * 9);
@@ -422,8 +431,6 @@ int camera_path(Ctx& c, const mvd_forward_args_t& a, std::unordered_map<std::str
   float* cat = c.talloc<float>((size_t)B * 2 * D);
   float* bufa = c.talloc<float>((size_t)B * (D > Hd ? D : Hd));
   float* bufb = c.talloc<float>((size_t)B * (D > Hd ? D : Hd));
-  float* emb = c.aalloc<float>((size_t)B * D);
-  c.e->cam_emb = emb; c.e->cam_batch = B;
   auto lin = [&](const std::string& k, const float* x, int ldx, int kin, int nout, float* y, int ldy) -> int {
     const float* w = c.WF("cam." + k + ".weight", (int64_t)nout * kin, 0);
     const float* b = c.WF("cam." + k + ".bias", nout, 0);
@@ -437,13 +444,12 @@ int camera_path(Ctx& c, const mvd_forward_args_t& a, std::unordered_map<std::str
     return mvd_launch_layernorm_f32(x, B, n, 1e-5f, g, b, silu, y, c.s);
   };
   if (!c.dry && !c.err) {
-    CHECK(mvd_launch_camera_features(a.source_camera, a.target_camera, B, a.cam_rows, nfreq, 10.0f, rflat, enc, c.s));
+    CHECK(mvd_launch_camera_features(src, tgt, B, cam_rows, nfreq, 10.0f, rflat, enc, c.s));
     // Q1: projection by the per-call random matrix (no bias)
-    CHECK(mvd_launch_skinny_linear(enc, encd, B, encd, a.fourier_proj, 0, nullptr, D, 0, encp, D, c.s));
+    CHECK(mvd_launch_skinny_linear(enc, encd, B, encd, proj, 0, nullptr, D, 0, encp, D, c.s));
   }
-  // rotation / translation encoders -> cat[:, :D] and cat[:, D:]
   const char* encs[2] = {"rotation_encoder", "translation_encoder"};
-  for (int t = 0; t < 2; ++t) {
+  for (int t = 0; t < 2; ++t) {   // -> cat[:, :D] and cat[:, D:]
     const std::string p = encs[t];
     const float* x = t == 0 ? rflat : encp;
     const int kin = t == 0 ? 9 : D;
@@ -462,22 +468,54 @@ int camera_path(Ctx& c, const mvd_forward_args_t& a, std::unordered_map<std::str
   CHECK(lin("final_projection.3", bufb, D, D, D, bufa, D));
   CHECK(lnorm("final_projection.4", bufa, D, 0, bufb));
   CHECK(lnorm("output_norm", bufb, D, 0, emb));
-  // modulators: name -> dim (mvd_unet.py:63-80); "mid" exists but is never addressed (hook asks for "mid_0", Q3)
+  return c.err;
+}
+
+// one modulator MLP: emb [B][D] -> processed FiLM scale/shift [B][dim]   (camera_encoder.py:215-222)
+int modulator(Ctx& c, const std::string& name, int dim, const float* emb, int B, float* sc, float* sh) {
+  const mvd_config_t& cfg = c.e->cfg;
+  const int D = cfg.cam_output_dim;
+  float* mh = c.talloc<float>((size_t)B * (D / 2));
+  float* mh2 = c.talloc<float>((size_t)B * (D / 2));
+  float* raw = c.talloc<float>((size_t)B * 2 * dim);
+  const std::string k = "cam.modulators." + name;
+  const float* w0 = c.WF(k + ".0.weight", (int64_t)(D / 2) * D, 0);
+  const float* b0 = c.WF(k + ".0.bias", D / 2, 0);
+  const float* g1 = c.WF(k + ".1.weight", D / 2, 0);
+  const float* b1 = c.WF(k + ".1.bias", D / 2, 0);
+  const float* w3 = c.WF(k + ".3.weight", (int64_t)2 * dim * (D / 2), 0);
+  const float* b3 = c.WF(k + ".3.bias", 2 * dim, 0);
+  if (c.err) return c.err;
+  if (c.dry) return 0;
+  CHECK(mvd_launch_skinny_linear(emb, D, B, D, w0, 0, b0, D / 2, 0, mh, D / 2, c.s));
+  CHECK(mvd_launch_layernorm_f32(mh, B, D / 2, 1e-5f, g1, b1, 1, mh2, c.s));
+  CHECK(mvd_launch_skinny_linear(mh2, D / 2, B, D / 2, w3, 0, b3, 2 * dim, 0, raw, 2 * dim, c.s));
+  return mvd_launch_film_params(raw, B, dim, cfg.cam_modulation_strength, sc, sh, c.s);
+}
+
+// modulators addressed by the hooks: name -> dim (mvd_unet.py:63-80); "mid" exists as a parameter but
+// is never addressed (the hook asks for "mid_0", Q3)
+std::vector<std::pair<std::string, int>> modulator_dims(const mvd_config_t& cfg, bool include_mid) {
   std::vector<std::pair<std::string, int>> mods;
   for (int i = 0; i < cfg.num_levels; ++i) mods.push_back({"down_" + std::to_string(i), cfg.block_out_channels[i]});
   for (int i = 0; i < cfg.num_levels; ++i) mods.push_back({"up_" + std::to_string(i), cfg.block_out_channels[cfg.num_levels - 1 - i]});
-  mods.push_back({"output", cfg.in_channels});
-  float* mh = c.talloc<float>((size_t)B * (D / 2));
-  float* mh2 = c.talloc<float>((size_t)B * (D / 2));
-  for (auto& m : mods) {
-    const int dim = m.second;
-    float* raw = c.talloc<float>((size_t)B * 2 * dim);
-    float* sc = c.aalloc<float>((size_t)B * dim);
-    float* sh = c.aalloc<float>((size_t)B * dim);
-    CHECK(lin("modulators." + m.first + ".0", emb, D, D, D / 2, mh, D / 2));
-    CHECK(lnorm("modulators." + m.first + ".1", mh, D / 2, 1, mh2));
-    CHECK(lin("modulators." + m.first + ".3", mh2, D / 2, D / 2, 2 * dim, raw, 2 * dim));
-    if (!c.dry && !c.err) CHECK(mvd_launch_film_params(raw, B, dim, cfg.cam_modulation_strength, sc, sh, c.s));
+  if (include_mid) mods.push_back({"mid", cfg.block_out_channels[cfg.num_levels - 1]});
+  mods.push_back({"output", 4});
+  return mods;
+}
+
+int camera_path(Ctx& c, const mvd_forward_args_t& a, std::unordered_map<std::string, std::pair<float*, float*>>& ss) {
+  const mvd_config_t& cfg = c.e->cfg;
+  const int B = a.batch, D = cfg.cam_output_dim;
+  float* emb = c.aalloc<float>((size_t)B * D);
+  c.e->cam_emb = emb; c.e->cam_batch = B;
+  CHECK(camera_embed(c, a.source_camera, a.target_camera, a.cam_rows, a.fourier_proj, B, emb));
+  for (auto& m : modulator_dims(cfg, false)) {
+    float* sc = c.aalloc<float>((size_t)B * m.second);
+    float* sh = c.aalloc<float>((size_t)B * m.second);
+    const size_t mk = c.e->tmp.off;
+    CHECK(modulator(c, m.first, m.second, emb, B, sc, sh));
+    c.e->tmp.off = mk;
     ss[m.first] = {sc, sh};
   }
   return c.err;
@@ -691,6 +729,38 @@ int mvd_engine_get_feature(mvd_engine_t* e, int idx, float* out_nchw, void* stre
   const int lv = e->feats[idx].level;
   return mvd_launch_nhwc_to_nchw_f32(e->feat_keep[idx], e->rc_batch, (e->rc_h >> lv) * (e->rc_w >> lv), e->feats[idx].C, out_nchw, (hipStream_t)stream);
 }
+// Standalone CameraEncoder.encode_cameras (camera_encoder.py:160-176) through the engine's kernels.
+int mvd_engine_encode_cameras(mvd_engine_t* e, const float* source_camera, const float* target_camera, int cam_rows,
+                              int batch, const float* fourier_proj, float* out_emb, void* stream) {
+  if (!e || !source_camera || !target_camera || !fourier_proj || !out_emb || batch <= 0 || (cam_rows != 3 && cam_rows != 4)) { mvd_set_error("encode_cameras: bad argument"); return -1; }
+  if (!e->ws_ptr) { mvd_set_error("encode_cameras: workspace not bound"); return -1; }
+  e->tmp.dry = false; e->tmp.base = (char*)e->ws_ptr; e->tmp.cap = (size_t)e->ws_bytes; e->tmp.off = e->tmp.high = 0;
+  Ctx c{e, (hipStream_t)stream, 0, false};
+  int r = camera_embed(c, source_camera, target_camera, cam_rows, fourier_proj, batch, out_emb);
+  if (!r && e->tmp.high > e->tmp.cap) { mvd_set_error("encode_cameras: workspace too small"); return -4; }
+  return r;
+}
+
+// Standalone CameraEncoder.apply_modulation_to_tensor (camera_encoder.py:207-255) on an NCHW fp32 tensor.
+// Unknown modulator names are the identity (returns 1 and leaves `out` untouched), like the reference.
+int mvd_engine_apply_modulation(mvd_engine_t* e, const char* name, const float* emb, int batch, const float* x_nchw,
+                                int channels, int hw, float* out_nchw, void* stream) {
+  if (!e || !name || !emb || !x_nchw || !out_nchw || batch <= 0 || channels <= 0 || hw <= 0) { mvd_set_error("apply_modulation: bad argument"); return -1; }
+  if (!e->ws_ptr) { mvd_set_error("apply_modulation: workspace not bound"); return -1; }
+  int dim = -1;
+  for (auto& m : modulator_dims(e->cfg, true)) if (m.first == name) dim = m.second;
+  if (dim < 0) return 1;
+  if (dim != channels) { mvd_set_error("apply_modulation: modulator '%s' has %d channels, tensor has %d", name, dim, channels); return -1; }
+  e->tmp.dry = false; e->tmp.base = (char*)e->ws_ptr; e->tmp.cap = (size_t)e->ws_bytes; e->tmp.off = e->tmp.high = 0;
+  Ctx c{e, (hipStream_t)stream, 0, false};
+  float* sc = c.talloc<float>((size_t)batch * dim);
+  float* sh = c.talloc<float>((size_t)batch * dim);
+  int r = modulator(c, name, dim, emb, batch, sc, sh);
+  if (r) return r;
+  if (e->tmp.high > e->tmp.cap) { mvd_set_error("apply_modulation: workspace too small"); return -4; }
+  return mvd_launch_film_nchw_f32(x_nchw, batch, channels, hw, sc, sh, out_nchw, (hipStream_t)stream);
+}
+
 int mvd_engine_get_camera_embedding(mvd_engine_t* e, float* out, void* stream) {
   if (!e || !out || !e->cam_emb) { mvd_set_error("get_camera_embedding: no camera pass yet"); return -1; }
   return (int)hipMemcpyAsync(out, e->cam_emb, (size_t)e->cam_batch * e->cfg.cam_output_dim * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream);
@@ -703,7 +773,7 @@ int mvd_op_linear(const void* a, const void* a2, int k1, int k2, const void* w, 
   MvdGemmArgs g; memset(&g, 0, sizeof(g));
   g.seg[0].p0 = (const bf16_t*)a; g.seg[0].p1 = (const bf16_t*)a2; g.seg[0].c0 = k1; g.seg[0].c1 = k2;
   g.seg[0].mode = MVD_A_DENSE; g.seg[0].ksize = k1 + k2; g.nseg = 1;
-  g.W = (const bf16_t*)w; g.M = m; g.N = n; g.Ktot = k1 + k2;
+  g.W = (const bf16_t*)w; g.M = m; g.N = n; g.Ktot = k1 + k2; g.ldw = k1 + k2;
   g.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : m; g.outH = 1; g.outW = g.rows_per_batch;
   g.bias = bias; g.rowvec = rowvec; g.ld_rowvec = ld_rowvec; g.res = (const bf16_t*)res;
   const int on = geglu ? n / 2 : n;
@@ -724,7 +794,7 @@ int mvd_op_conv3x3(const void* x, int batch, int in_h, int in_w, int cin, int st
     g.seg[1].p0 = (const bf16_t*)sc; g.seg[1].p1 = (const bf16_t*)sc2; g.seg[1].c0 = sc_c1; g.seg[1].c1 = sc_c2;
     g.seg[1].mode = MVD_A_DENSE; g.seg[1].ksize = sc_c1 + sc_c2; g.nseg = 2; g.Ktot += sc_c1 + sc_c2;
   }
-  g.W = (const bf16_t*)w; g.M = batch * oh * ow; g.N = cout; g.rows_per_batch = oh * ow; g.outH = oh; g.outW = ow;
+  g.W = (const bf16_t*)w; g.ldw = g.Ktot; g.M = batch * oh * ow; g.N = cout; g.rows_per_batch = oh * ow; g.outH = oh; g.outW = ow;
   g.bias = bias; g.rowvec = rowvec; g.ld_rowvec = ld_rowvec; g.res = (const bf16_t*)res; g.ldres = cout; g.alpha = 1.f;
   g.out = out; g.ldo = cout;
   return mvd_launch_gemm(g, (hipStream_t)stream, force_cfg);

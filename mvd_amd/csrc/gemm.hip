@@ -117,7 +117,7 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(const MvdGemmArgs a) {
     for (int i = 0; i < C::B_IT; ++i) {
       const int row = lrow + i * C::ROWS_PER_IT;
       if (C::B_CHUNKS % C::NT == 0 || row < C::BN)
-        rb[i] = *reinterpret_cast<const u32x4*>(a.W + (size_t)(n0 + row) * a.Ktot + kt * 64 + kc * 8);
+        rb[i] = *reinterpret_cast<const u32x4*>(a.W + (size_t)(n0 + row) * a.ldw + kt * 64 + kc * 8);
     }
   };
   auto store_stage = [&](int st) {
@@ -268,6 +268,7 @@ int mvd_launch_gemm(const MvdGemmArgs& a, hipStream_t s, int force_cfg) {
   }
   if (a.nseg == 2 && a.seg[0].mode == MVD_A_CONV3 && a.seg[1].mode == MVD_A_CONV3) { mvd_set_error("gemm: two conv segments unsupported"); return -1; }
   if (ksum != a.Ktot) { mvd_set_error("gemm: segment K sum %d != Ktot %d", ksum, a.Ktot); return -1; }
+  if (a.ldw < a.Ktot || (a.ldw % 8) || !a.W) { mvd_set_error("gemm: bad weight stride ldw=%d (K=%d)", a.ldw, a.Ktot); return -1; }
   if (a.rows_per_batch <= 0) { mvd_set_error("gemm: rows_per_batch must be > 0"); return -1; }
   if (a.N % 64) { mvd_set_error("gemm: N=%d must be a multiple of 64", a.N); return -1; }
   if (a.geglu && (a.out_f32 || a.res || a.rowvec)) { mvd_set_error("gemm: unsupported GEGLU epilogue combination"); return -1; }

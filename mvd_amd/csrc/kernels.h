@@ -24,7 +24,8 @@ struct MvdASeg {          // one K segment of the A operand
 struct MvdGemmArgs {
   MvdASeg seg[2];
   int nseg;
-  const bf16_t* W;        // [N][Ktot] bf16, K contiguous
+  const bf16_t* W;        // [N][ldw] bf16, K contiguous
+  int ldw;                // row stride of W in elements (>= Ktot)
   int M, N, Ktot;
   int rows_per_batch;     // pixels per batch element (conv geometry + per-batch epilogue vector)
   int outH, outW;         // conv output spatial size
@@ -101,5 +102,9 @@ int mvd_launch_camera_features(const float* src, const float* tgt, int batch, in
 // FiLM post-processing: raw [batch][2*dim] -> scale = 2*sigmoid(raw[:dim])*k, shift = raw[dim:]*k
 int mvd_launch_film_params(const float* raw, int batch, int dim, float strength, float* scale, float* shift,
                            hipStream_t s);
+
+// FiLM on an NCHW fp32 tensor (standalone CameraEncoder.apply_modulation); scale/shift [batch][c]
+int mvd_launch_film_nchw_f32(const float* x, int batch, int c, int hw, const float* scale, const float* shift, float* y,
+                             hipStream_t s);
 
 void mvd_set_error(const char* fmt, ...);

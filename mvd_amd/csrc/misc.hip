@@ -219,6 +219,14 @@ __global__ void film_params_kernel(const float* __restrict__ raw, int dim, float
   shift[i] = t * strength;
 }
 
+__global__ void film_nchw_f32_kernel(const float* __restrict__ x, int c, int hw, const float* __restrict__ scale,
+                                     const float* __restrict__ shift, float* __restrict__ y, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long bc = i / hw;   // b*c + ch
+  y[i] = fmaf(x[i], scale[bc], shift[bc]);
+}
+
 int check(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { mvd_set_error("%s launch: %s", what, hipGetErrorString(e)); return -3; }
@@ -303,4 +311,12 @@ int mvd_launch_film_params(const float* raw, int batch, int dim, float strength,
   const int total = batch * dim;
   hipLaunchKernelGGL(film_params_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, raw, dim, strength, scale, shift, total);
   return check("film_params");
+}
+
+int mvd_launch_film_nchw_f32(const float* x, int batch, int c, int hw, const float* scale, const float* shift, float* y,
+                             hipStream_t s) {
+  if (!x || !y || !scale || !shift || batch <= 0 || c <= 0 || hw <= 0) { mvd_set_error("film_nchw: bad arguments"); return -1; }
+  const long total = (long)batch * c * hw;
+  hipLaunchKernelGGL(film_nchw_f32_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, x, c, hw, scale, shift, y, total);
+  return check("film_nchw");
 }

@@ -91,6 +91,7 @@ def pack_unet(sd: Dict[str, torch.Tensor], cfg: UNetConfig, device, adapter: boo
             wo, bo = f(f"{b}.{a}.to_out.0.weight"), f(f"{b}.{a}.to_out.0.bias")
             if adapter:
                 pr = f"{b}.{a}.processor"
+                out[f"{key}.{a}.out.b0"] = _f32(bo, device)      # plain bias for passes without the adapter
                 wo = torch.cat([wo, ref_scale * f(f"{pr}.to_out_ref.0.weight")], dim=1)
                 bo = bo + ref_scale * f(f"{pr}.to_out_ref.0.bias")
             out[f"{key}.{a}.out.w"] = _bf(wo, device)

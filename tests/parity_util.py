@@ -1,0 +1,85 @@
+"""Shared end-to-end parity harness: HIP engine (through the MultiViewUNet mirror and the C ABI)
+vs the CPU oracle on identical seeded inputs and identical weights."""
+from __future__ import annotations
+
+import time
+
+import torch
+
+from oracle import mvd as OM
+from oracle import sd21_unet as OU
+
+
+def rel_l2(got: torch.Tensor, want: torch.Tensor) -> float:
+    return ((got.float().cpu() - want.float()).norm() / want.float().norm().clamp_min(1e-12)).item()
+
+
+def max_rel(got: torch.Tensor, want: torch.Tensor) -> float:
+    return ((got.float().cpu() - want.float()).abs().max() / want.float().abs().max().clamp_min(1e-12)).item()
+
+
+def look_at(azim_deg: float, elev_deg: float = 20.0, radius: float = 2.0) -> torch.Tensor:
+    """4x4 camera-to-world look-at pose on a sphere (SURVEY.md 8d synthetic cameras)."""
+    import math
+    a, e = math.radians(azim_deg), math.radians(elev_deg)
+    pos = torch.tensor([radius * math.cos(e) * math.sin(a), radius * math.sin(e), radius * math.cos(e) * math.cos(a)])
+    fwd = -pos / pos.norm()
+    up = torch.tensor([0.0, 1.0, 0.0])
+    right = torch.linalg.cross(fwd, up)
+    right = right / right.norm()
+    nup = torch.linalg.cross(right, fwd)
+    m = torch.eye(4)
+    m[:3, 0], m[:3, 1], m[:3, 2], m[:3, 3] = right, nup, -fwd, pos
+    return m
+
+
+def make_inputs(cfg: OU.UNetConfig, batch: int, hw: int, text_len: int, seed: int = 0, cam_dim: int = 1024):
+    g = torch.Generator().manual_seed(seed)
+    sample = torch.randn(batch, cfg.in_channels, hw, hw, generator=g)
+    text = torch.randn(batch, text_len, cfg.cross_attention_dim, generator=g)
+    lat = 0.18215 * torch.randn(batch, cfg.in_channels, hw, hw, generator=g)
+    src = torch.stack([look_at(0.0)] * batch)
+    tgt = torch.stack([look_at([45.0, 90.0, 180.0, 270.0][b % 4]) for b in range(batch)])
+    proj = OM.draw_fourier_projection(cam_dim, g)
+    return dict(sample=sample, text=text, lat=lat, src=src, tgt=tgt, proj=proj)
+
+
+def build_pair(cfg_name: str = "tiny", seed: int = 0, cam_dim: int = 1024, cam_hidden: int = 512, img_ref_scale=0.3,
+               cam_strength=0.2):
+    """(oracle cfg, oracle params, MultiViewUNet mirror on cuda) sharing one set of seeded weights."""
+    from mvd_amd.config import UNetConfig
+    from mvd_amd.mvd_unet import MultiViewUNet
+    ocfg = OU.UNetConfig.tiny() if cfg_name == "tiny" else OU.UNetConfig.sd21()
+    hcfg = UNetConfig.tiny() if cfg_name == "tiny" else UNetConfig.sd21()
+    params = OM.init_mvd_params(ocfg, seed, cam_dim=cam_dim, cam_hidden=cam_hidden)
+    model = MultiViewUNet(None, unet_config=hcfg, init="empty", img_ref_scale=img_ref_scale,
+                          cam_modulation_strength=cam_strength, cam_output_dim=cam_dim, cam_hidden_dim=cam_hidden)
+    missing, unexpected = model.load_state_dict(params, strict=False)
+    assert not unexpected, unexpected[:5]
+    assert not missing, missing[:5]
+    model = model.to("cuda")
+    model.eval()
+    return ocfg, params, model
+
+
+def run_tiny_parity(batch: int = 2, verbose: bool = False, cfg_name: str = "tiny", hw: int = 16, text_len: int = 7,
+                    timestep: int = 500):
+    cam_dim, cam_hidden = (96, 48) if cfg_name == "tiny" else (1024, 512)
+    ocfg, params, model = build_pair(cfg_name, 0, cam_dim, cam_hidden)
+    inp = make_inputs(ocfg, batch, hw, text_len, 0, cam_dim)
+    t0 = time.time()
+    feats = {}
+    want = OM.multiview_unet_forward(params, ocfg, inp["sample"], torch.tensor(timestep), inp["text"], inp["src"],
+                                     inp["tgt"], inp["lat"], fourier_proj=inp["proj"], img_ref_scale=0.3,
+                                     cam_modulation_strength=0.2, features_out=feats)
+    t_cpu = time.time() - t0
+    model.fourier_projection = inp["proj"]
+    with torch.no_grad():
+        got = model(inp["sample"].cuda(), torch.tensor(timestep), inp["text"].cuda(), source_camera=inp["src"].cuda(),
+                    target_camera=inp["tgt"].cuda(), source_image_latents=inp["lat"].cuda()).sample
+    torch.cuda.synchronize()
+    stats = dict(rel_l2=rel_l2(got, want), max_rel=max_rel(got, want), cpu_seconds=t_cpu,
+                 finite=bool(torch.isfinite(got).all()))
+    if verbose:
+        print("parity", cfg_name, f"batch={batch}", stats, flush=True)
+    return stats
