@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""Headline benchmark: UNet forward-passes/sec at 512x512 (64x64x4 latent, 77 text tokens) for the
+SD-2.1 UNet + MVD camera/cross-view adapter hot path on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W            (single GPU)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU)
+
+A "step" is one ``MultiViewUNet.forward`` over one batch of synthetic (source -> target) pairs that
+is already resident in HBM.  The default workload is BASELINE.json configs[3] per GPU (8 objects x 4
+target views = 32 pairs, camera + image conditioning on); configs[4] is that shard on each of N GPUs
+(weak scaling; the only collective is the start-up RCCL weight broadcast).  By default the forward
+is reference-faithful ("cold"): the frozen reference-image UNet is re-run every step exactly as
+/root/reference/src/models/mvd_unet.py:287-291 does; ``--cached`` reuses its step-invariant K/V (Q5).
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+# algorithmic FLOPs per (source -> target) pair per forward (2*MAC over convs, linears, QK^T/PV): SURVEY.md 8d
+F_BASE, F_ADAPTER_MAIN, F_ENCODER = 804.26e9, 1151.59e9, 804.26e9
+PEAK_BF16_MFMA = 2.5e15          # dense, /opt/skills/guides/MI355X_MICROARCH.md:43
+PEAK_HBM = 8.0e12
+
+WORKLOADS = {
+    # name: (pairs per GPU, camera, image conditioning, description)
+    "cfg4": (32, True, True, "configs[3]/[4]: 8 objects x 4 target views per GPU (32 pairs), camera FiLM + cross-view adapter"),
+    "cfg3": (1, True, True, "configs[2]: 1 source -> 1 target view, camera FiLM + cross-view adapter"),
+    "cfg2": (1, False, False, "configs[1]: base SD2.1 UNet, batch 1, both conditionings off"),
+}
+
+
+def fill_synthetic_weights(model, seed: int = 0):
+    """Seeded variance-preserving random weights directly on the GPU (no pretrained SD-2.1 weights exist offline)."""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if p.ndim >= 2:
+                fan_in = p[0].numel()
+                p.copy_(torch.randn(p.shape, generator=g, device="cuda") / math.sqrt(fan_in))
+            elif name.endswith("weight"):      # every 1-D weight is a GroupNorm / LayerNorm scale
+                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g, device="cuda"))
+            else:
+                p.copy_(0.1 * torch.randn(p.shape, generator=g, device="cuda"))
+    model.mark_weights_changed()
+
+
+def make_batch(pairs: int, rank: int, device):
+    from tests.parity_util import look_at
+    g = torch.Generator().manual_seed(1000 + rank)
+    objs = max(1, pairs // 4)
+    views = pairs // objs
+    sample = torch.randn(pairs, 4, 64, 64, generator=g)
+    text = torch.randn(objs, 77, 1024, generator=g).repeat_interleave(views, 0)
+    lat = (0.18215 * torch.randn(objs, 4, 64, 64, generator=g)).repeat_interleave(views, 0)   # pipeline.py:111-113
+    src = torch.stack([look_at(0.0)] * pairs)
+    tgt = torch.stack([look_at([45.0, 90.0, 180.0, 270.0][i % 4]) for i in range(pairs)])
+    t = torch.full((pairs,), 500.0)
+    return {k: v.to(device).contiguous() for k, v in dict(sample=sample, text=text, lat=lat, src=src, tgt=tgt, t=t).items()}
+
+
+def cpu_baseline(timed_runs: int = 1):
+    """The oracle (CPU fp32 restatement, oracle/mvd.py) timed on this box's host cores: configs[2]
+    (B=1, adapter + camera on, cold forward).  ~10 s per forward on 16 cores."""
+    from oracle import mvd as OM
+    from oracle import sd21_unet as OU
+    from tests.parity_util import make_inputs
+    # torch's default intra-op thread count (the box's usable cores); os.cpu_count() reports all 256 host
+    # threads of the node and over-subscribing them makes the forward 30x slower
+    cores = torch.get_num_threads()
+    cfg = OU.UNetConfig.sd21()
+    params = OM.init_mvd_params(cfg, 0, share_encoder=True)
+    inp = make_inputs(cfg, 1, 64, 77, 0, 1024)
+    times = []
+    with torch.no_grad():
+        for i in range(timed_runs):
+            t0 = time.perf_counter()
+            OM.multiview_unet_forward(params, cfg, inp["sample"], torch.tensor(500), inp["text"], inp["src"], inp["tgt"],
+                                      inp["lat"], fourier_proj=inp["proj"])
+            times.append(time.perf_counter() - t0)
+    best = min(times)
+    return {"value": 1.0 / best, "unit": "forward-passes/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/mvd.py, configs[2] (B=1, 64x64 latent, adapter+camera on, cold forward = {(F_ADAPTER_MAIN + F_ENCODER) / 1e9:.0f} GFLOP), "
+                      f"{timed_runs} timed forward(s), torch fp32 on {cores} host threads (os.cpu_count()={os.cpu_count()}), {best:.2f} s/forward"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=list(WORKLOADS), default="cfg4")
+    ap.add_argument("--pairs", type=int, default=0, help="override pairs per GPU")
+    ap.add_argument("--cached", action="store_true", help="reuse the step-invariant reference K/V (Q5) instead of re-running the encoder")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    from mvd_amd import distributed as D
+    rank, world, local = D.init_from_env("nccl")
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from mvd_amd.config import UNetConfig
+    from mvd_amd.mvd_unet import MultiViewUNet
+    pairs, use_cam, use_img, desc = WORKLOADS[args.workload]
+    if args.pairs:
+        pairs = args.pairs
+
+    # ---- model: rank 0 creates the synthetic weights, every rank packs buffers, one RCCL broadcast
+    model = MultiViewUNet(None, unet_config=UNetConfig.sd21(), init="empty", img_ref_scale=0.3,
+                          cam_modulation_strength=0.2, cache_reference=args.cached).to(dev)
+    model.eval()
+    if rank == 0:
+        fill_synthetic_weights(model, 0)
+    else:
+        with torch.no_grad():
+            for p in model.parameters():
+                p.zero_()
+        model.mark_weights_changed()
+    eng = model._sync_engine()
+    bc = D.broadcast_engine_weights(eng, 0)
+    weight_bytes = eng.weight_bytes()
+    for p in model.parameters():           # fp32 masters are no longer needed on the device
+        p.data = torch.empty(0, device=dev)
+    model._dirty = False
+    torch.cuda.empty_cache()
+
+    batch = make_batch(pairs, rank, dev)
+    kw = {}
+    if use_cam:
+        kw.update(source_camera=batch["src"], target_camera=batch["tgt"])
+    if use_img:
+        kw.update(source_image_latents=batch["lat"])
+
+    def step():
+        with torch.no_grad():
+            return model(batch["sample"], batch["t"], batch["text"], **kw).sample
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all(), "non-finite UNet output"
+    D.barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    D.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = D.max_over_ranks(elapsed, dev)
+    gpu_ms = e0.elapsed_time(e1)
+
+    forward_kind = "base" if not use_img else ("cached" if args.cached else "cold")
+    flops_pair = F_BASE if not use_img else (F_ADAPTER_MAIN if args.cached else F_ADAPTER_MAIN + F_ENCODER)
+    total_pairs = pairs * world
+    value = total_pairs * args.steps / elapsed
+
+    # ---- per-kernel-class timing with HIP events on the launch stream (rank 0, after the timed region)
+    roofline = None
+    classes = {}
+    if not args.no_profile:
+        nprof = min(args.steps, 3)
+        eng.set_profiling(True)
+        for _ in range(nprof):
+            step()
+        torch.cuda.synchronize()
+        classes = eng.profile_summary()
+        eng.set_profiling(False)
+        tot_ms = sum(c["ms"] for c in classes.values())
+        mf = {k: c for k, c in classes.items() if c["flops"] > 0}
+        if mf:
+            dom = max(mf, key=lambda k: mf[k]["ms"])
+            c = mf[dom]
+            ach = c["flops"] / (c["ms"] * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA / 1e12,
+                        "unit": "TFLOP/s", "frac": round(ach * 1e12 / PEAK_BF16_MFMA, 4), "traffic": None,
+                        "avg_launch_us": round(c["ms"] * 1e3 / c["launches"], 2), "launches_per_step": c["launches"] // nprof,
+                        "share_of_step_time": round(c["ms"] / tot_ms, 3),
+                        "measured_over": f"{nprof} profiled steps after the timed region (HIP events on the launch stream)",
+                        "whole_forward_achieved": round(total_pairs * args.steps * flops_pair / elapsed / world / 1e12, 2),
+                        "whole_forward_frac": round(total_pairs * args.steps * flops_pair / elapsed / world / PEAK_BF16_MFMA, 4)}
+            for k in classes:
+                classes[k] = {"launches": classes[k]["launches"] // nprof, "ms_per_step": round(classes[k]["ms"] / nprof, 3),
+                              "tflops": round(classes[k]["flops"] / max(classes[k]["ms"], 1e-9) / 1e9, 1) if classes[k]["flops"] else None,
+                              "gbps": round(classes[k]["bytes"] / max(classes[k]["ms"], 1e-9) / 1e6, 1) if classes[k]["bytes"] else None}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(1)
+
+    if rank == 0:
+        line = {
+            "metric": "UNet forward-passes/sec @512x512 SD2.1+MV adapter", "value": round(value, 3),
+            "unit": "forward-passes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {desc}", "pairs_per_gpu": pairs, "global_pairs": total_pairs,
+                       "latent": "64x64x4", "text_tokens": 77, "forward": forward_kind,
+                       "gflop_per_pair": round(flops_pair / 1e9, 2), "parallelism": f"dp{world} (pairs sharded by object)",
+                       "weights": "synthetic seeded, SD2.1 shapes (865.9M UNet x2 + 99.2M adapter + 19.1M camera)"},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "gpu_ms_per_step_events": round(gpu_ms / args.steps, 3),
+            "weight_bytes_bf16_packed": weight_bytes,
+            "weight_broadcast": {"bytes": bc["bytes"], "seconds": round(bc["seconds"], 4), "buckets": bc["buckets"]},
+            "kernel_classes": classes,
+        }
+        print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

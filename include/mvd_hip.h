@@ -96,6 +96,11 @@ typedef struct {
 
 int mvd_unet_forward(mvd_engine_t* e, const mvd_forward_args_t* args, void* stream);
 
+/* Per-kernel-class timing with HIP events on the launch stream (measurement only; off by default).
+ * classes: 0..5 GEMM/conv tile config, 8..11 attention (1,2,4,8 waves), 16 groupnorm, 17 layernorm. */
+int mvd_engine_set_profiling(mvd_engine_t* e, int enable);
+int mvd_engine_profile_summary(mvd_engine_t* e, int cap, int* cls, int* launches, double* ms, double* flops, double* bytes);
+
 /* Number / shape / copy-out (NCHW fp32) of the encoder feature maps (image_encoder.py:36-84). */
 int mvd_engine_num_features(mvd_engine_t* e);
 int mvd_engine_feature_shape(mvd_engine_t* e, int idx, int* channels, int* height, int* width);

@@ -48,6 +48,9 @@ _SIGS = {
     "mvd_engine_refcache_bytes": (C.c_int64, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "mvd_engine_bind_workspace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),
     "mvd_unet_forward": (C.c_int, [C.c_void_p, C.POINTER(mvd_forward_args_t), C.c_void_p]),
+    "mvd_engine_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "mvd_engine_profile_summary": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                             C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "mvd_engine_num_features": (C.c_int, [C.c_void_p]),
     "mvd_engine_feature_shape": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mvd_engine_get_feature": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

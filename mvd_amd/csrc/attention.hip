@@ -223,6 +223,8 @@ int launch_nw(const MvdAttnArgs& a, int maxq, hipStream_t s) {
 
 }  // namespace
 
+int mvd_attention_pick_nw(const MvdAttnArgs& a);
+
 int mvd_launch_attention(const MvdAttnArgs& a, hipStream_t s) {
   if (a.nprob < 1 || a.nprob > 2 || a.batch <= 0 || a.heads <= 0) { mvd_set_error("attention: bad problem count/batch/heads"); return -1; }
   int maxq = 0;
@@ -234,10 +236,22 @@ int mvd_launch_attention(const MvdAttnArgs& a, hipStream_t s) {
     if ((p.bsq % 8) || (p.bsk % 8) || (p.bsv % 8) || (p.bso % 4)) { mvd_set_error("attention: bad batch strides in problem %d", i); return -1; }
     maxq = p.nq > maxq ? p.nq : maxq;
   }
-  // enough workgroups to fill 256 CUs: prefer 8 waves (256 queries) per workgroup, shrink for small problems
+  switch (mvd_attention_pick_nw(a)) {
+    case 3: return launch_nw<8>(a, maxq, s);
+    case 2: return launch_nw<4>(a, maxq, s);
+    case 1: return launch_nw<2>(a, maxq, s);
+    default: return launch_nw<1>(a, maxq, s);
+  }
+}
+
+// log2 of the waves per workgroup: enough workgroups to fill 256 CUs, prefer 8 waves (256 queries),
+// shrink for small problems
+int mvd_attention_pick_nw(const MvdAttnArgs& a) {
+  int maxq = 0;
+  for (int i = 0; i < a.nprob; ++i) maxq = a.p[i].nq > maxq ? a.p[i].nq : maxq;
   const long heads_total = (long)a.heads * a.batch * a.nprob;
-  if (maxq >= 256 && heads_total * ((maxq + 255) / 256) >= 512) return launch_nw<8>(a, maxq, s);
-  if (maxq >= 128 && heads_total * ((maxq + 127) / 128) >= 512) return launch_nw<4>(a, maxq, s);
-  if (maxq >= 64) return launch_nw<2>(a, maxq, s);
-  return launch_nw<1>(a, maxq, s);
+  if (maxq >= 256 && heads_total * ((maxq + 255) / 256) >= 512) return 3;
+  if (maxq >= 128 && heads_total * ((maxq + 127) / 128) >= 512) return 2;
+  if (maxq >= 64) return 1;
+  return 0;
 }

@@ -61,7 +61,20 @@ struct mvd_engine {
   float* cam_emb = nullptr; int cam_batch = 0;
   std::vector<int> temb_off;        // per resnet offset into the fused time_emb_proj output
   int temb_total = 0;
+  // optional per-kernel-class profiling (HIP events on the launch stream)
+  bool prof = false;
+  struct ProfRec { int cls; double flops; double bytes; hipEvent_t e0, e1; };
+  std::vector<ProfRec> prof_recs;
+  std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
+  hipEvent_t get_event() {
+    if (ev_used == ev_pool.size()) { hipEvent_t ev; hipEventCreate(&ev); ev_pool.push_back(ev); }
+    return ev_pool[ev_used++];
+  }
 };
+
+// profiling classes: 0..5 = gemm tile config, 8..11 = attention NW (1,2,4,8), 16 groupnorm, 17 layernorm, 18 other
+int mvd_gemm_pick_config(const MvdGemmArgs& a);
+int mvd_attention_pick_nw(const MvdAttnArgs& a);
 
 namespace {
 
@@ -99,7 +112,20 @@ struct Ctx {
   }
 
   // ------------------------------------------------------------------ op wrappers
-  int gemm(MvdGemmArgs& g) { if (err) return err; if (dry) return 0; return mvd_launch_gemm(g, s); }
+  template <class F> int profiled(int cls, double flops, double bytes, F&& launch) {
+    if (!e->prof) return launch();
+    hipEvent_t e0 = e->get_event(), e1 = e->get_event();
+    hipEventRecord(e0, s);
+    const int r = launch();
+    hipEventRecord(e1, s);
+    e->prof_recs.push_back({cls, flops, bytes, e0, e1});
+    return r;
+  }
+  int gemm(MvdGemmArgs& g) {
+    if (err) return err; if (dry) return 0;
+    const double fl = 2.0 * g.M * (double)g.N * g.Ktot;
+    return profiled(e->prof ? mvd_gemm_pick_config(g) : 0, fl, 0.0, [&] { return mvd_launch_gemm(g, s); });
+  }
 
   // dense linear: out[M][N] = alpha*(A.W^T + bias) + res
   int linear(const bf16_t* a, const bf16_t* a2, int k1, int k2, int M, const bf16_t* w, const float* bias, int N,
@@ -134,13 +160,19 @@ struct Ctx {
     const int groups = e->cfg.norm_num_groups;
     float* ws = talloc<float>((size_t)B * MVD_GN_MAXCHUNK * groups * 2);
     if (dry) return 0;
-    return mvd_launch_groupnorm(x0, x1, c0, c1, B, hw, groups, eps, g, b, silu, y, ws, s);
+    const double by = 3.0 * B * (double)hw * (c0 + c1) * 2;   // 2 reads + 1 write of the activation
+    return profiled(16, 0.0, by, [&] { return mvd_launch_groupnorm(x0, x1, c0, c1, B, hw, groups, eps, g, b, silu, y, ws, s); });
   }
   int layernorm(const bf16_t* x, int rows, int c, const float* g, const float* b, bf16_t* y) {
     if (err) return err; if (dry) return 0;
-    return mvd_launch_layernorm(x, rows, c, 1e-5f, g, b, y, s);
+    return profiled(17, 0.0, 2.0 * rows * (double)c * 2, [&] { return mvd_launch_layernorm(x, rows, c, 1e-5f, g, b, y, s); });
   }
-  int attention(MvdAttnArgs& a) { if (err) return err; if (dry) return 0; return mvd_launch_attention(a, s); }
+  int attention(MvdAttnArgs& a) {
+    if (err) return err; if (dry) return 0;
+    double fl = 0;
+    for (int i = 0; i < a.nprob; ++i) fl += 4.0 * a.batch * a.heads * (double)a.p[i].nq * a.p[i].nk * 64;
+    return profiled(e->prof ? 8 + mvd_attention_pick_nw(a) : 8, fl, 0.0, [&] { return mvd_launch_attention(a, s); });
+  }
 };
 
 // ---------------------------------------------------------------------- structure helpers
@@ -715,6 +747,30 @@ int mvd_unet_forward(mvd_engine_t* e, const mvd_forward_args_t* args, void* stre
   e->act.base = (char*)e->ws_ptr; e->act.cap = act_bytes;
   e->tmp.base = (char*)e->ws_ptr + act_bytes; e->tmp.cap = (size_t)e->ws_bytes - act_bytes;
   return forward_impl(e, *args, (hipStream_t)stream, false);
+}
+
+int mvd_engine_set_profiling(mvd_engine_t* e, int enable) {
+  if (!e) { mvd_set_error("set_profiling: null engine"); return -1; }
+  e->prof = enable != 0; e->prof_recs.clear(); e->ev_used = 0;
+  return 0;
+}
+
+// Sums the recorded launches per kernel class (after synchronising the last event) and resets the records.
+// Arrays hold `cap` entries; returns the number of classes written (<0 on error).
+int mvd_engine_profile_summary(mvd_engine_t* e, int cap, int* cls, int* launches, double* ms, double* flops, double* bytes) {
+  if (!e || cap <= 0 || !cls || !launches || !ms || !flops || !bytes) { mvd_set_error("profile_summary: bad argument"); return -1; }
+  int n = 0;
+  for (auto& r : e->prof_recs) {
+    if (hipEventSynchronize(r.e1) != hipSuccess) { mvd_set_error("profile_summary: event sync failed"); return -2; }
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) { mvd_set_error("profile_summary: elapsed time failed"); return -2; }
+    int j = 0;
+    while (j < n && cls[j] != r.cls) ++j;
+    if (j == n) { if (n == cap) continue; cls[n] = r.cls; launches[n] = 0; ms[n] = 0; flops[n] = 0; bytes[n] = 0; ++n; }
+    launches[j] += 1; ms[j] += t; flops[j] += r.flops; bytes[j] += r.bytes;
+  }
+  e->prof_recs.clear(); e->ev_used = 0;
+  return n;
 }
 
 int mvd_engine_num_features(mvd_engine_t* e) { return e ? (int)e->feats.size() : -1; }

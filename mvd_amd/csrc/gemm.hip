@@ -250,6 +250,20 @@ constexpr int kNumCfgs = 6;
 
 extern "C" int mvd_gemm_num_configs(void) { return kNumCfgs; }
 
+// largest tile that still yields >= ~2 blocks per CU; otherwise the config with most blocks
+int mvd_gemm_pick_config(const MvdGemmArgs& a) {
+  int cfg = -1;
+  long best_blocks = -1;
+  for (int c = 0; c < kNumCfgs; ++c) {
+    if (a.N % kCfgs[c].bn) continue;
+    if (a.geglu && !kCfgs[c].tn_even) continue;
+    const long blocks = (long)((a.M + kCfgs[c].bm - 1) / kCfgs[c].bm) * (a.N / kCfgs[c].bn);
+    if (blocks >= 480) return c;
+    if (blocks > best_blocks) { best_blocks = blocks; cfg = c; }
+  }
+  return cfg;
+}
+
 int mvd_launch_gemm(const MvdGemmArgs& a, hipStream_t s, int force_cfg) {
   // ---- host-side shape validation: a wrong shape must never reach the kernel
   if (a.M <= 0 || a.N <= 0 || a.Ktot <= 0 || a.nseg < 1 || a.nseg > 2) { mvd_set_error("gemm: bad dims M=%d N=%d K=%d nseg=%d", a.M, a.N, a.Ktot, a.nseg); return -1; }
@@ -276,17 +290,7 @@ int mvd_launch_gemm(const MvdGemmArgs& a, hipStream_t s, int force_cfg) {
   if (a.ldo < on || (a.ldo % 4) || (a.res && (a.ldres % 4))) { mvd_set_error("gemm: bad leading dims"); return -1; }
 
   int cfg = force_cfg;
-  if (cfg < 0) {
-    // largest tile that still yields >= ~2 blocks per CU; otherwise the config with most blocks
-    long best_blocks = -1;
-    for (int c = 0; c < kNumCfgs; ++c) {
-      if (a.N % kCfgs[c].bn) continue;
-      if (a.geglu && !kCfgs[c].tn_even) continue;
-      const long blocks = (long)((a.M + kCfgs[c].bm - 1) / kCfgs[c].bm) * (a.N / kCfgs[c].bn);
-      if (blocks >= 480) { cfg = c; break; }
-      if (blocks > best_blocks) { best_blocks = blocks; cfg = c; }
-    }
-  }
+  if (cfg < 0) cfg = mvd_gemm_pick_config(a);
   if (cfg < 0 || cfg >= kNumCfgs || a.N % kCfgs[cfg].bn || (a.geglu && !kCfgs[cfg].tn_even)) { mvd_set_error("gemm: no tile config for N=%d geglu=%d cfg=%d", a.N, a.geglu, cfg); return -1; }
   switch (cfg) {
     case 0: return launch_cfg<C0>(a, s);

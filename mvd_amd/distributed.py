@@ -1,0 +1,92 @@
+"""Multi-GPU support for the hot path: one process per GPU, pairs sharded by object, and ONE
+collective -- the start-up broadcast of the packed weights from rank 0 (RCCL over xGMI when the
+backend is "nccl").  There is no per-forward collective: the denoising path has no cross-pair
+data flow (replica-local Q2 statistics)."""
+from __future__ import annotations
+
+import os
+import time
+from typing import Dict, Iterable, List, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str = "nccl") -> tuple:
+    """(rank, world, local_rank); initialises torch.distributed when WORLD_SIZE > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(n_items: int, rank: int, world: int) -> range:
+    """Contiguous shard of ``n_items`` objects for ``rank`` (keeps an object's views on one GPU)."""
+    base, rem = divmod(n_items, world)
+    start = rank * base + min(rank, rem)
+    return range(start, start + base + (1 if rank < rem else 0))
+
+
+def broadcast_tensors(tensors: Sequence[torch.Tensor], src: int = 0, bucket_bytes: int = 256 << 20) -> Dict[str, float]:
+    """In-place broadcast of ``tensors`` from ``src``.  Tensors are coalesced into flat buckets per
+    dtype (few large transfers: a ring broadcast over xGMI is per-link bound, so large messages)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return dict(bytes=0, seconds=0.0, buckets=0)
+    t0 = time.perf_counter()
+    total = 0
+    nb = 0
+    by_dtype: Dict[torch.dtype, List[torch.Tensor]] = {}
+    for t in tensors:
+        by_dtype.setdefault(t.dtype, []).append(t)
+    for dtype, ts in by_dtype.items():
+        bucket: List[torch.Tensor] = []
+        size = 0
+
+        def flush():
+            nonlocal bucket, size, total, nb
+            if not bucket:
+                return
+            flat = torch.cat([b.reshape(-1) for b in bucket])
+            dist.broadcast(flat, src)
+            off = 0
+            for b in bucket:
+                n = b.numel()
+                b.copy_(flat[off:off + n].view_as(b))
+                off += n
+            total += flat.numel() * flat.element_size()
+            nb += 1
+            bucket, size = [], 0
+
+        for t in ts:
+            bucket.append(t)
+            size += t.numel() * t.element_size()
+            if size >= bucket_bytes:
+                flush()
+        flush()
+    if tensors and tensors[0].is_cuda:
+        torch.cuda.synchronize()
+    return dict(bytes=total, seconds=time.perf_counter() - t0, buckets=nb)
+
+
+def broadcast_engine_weights(engine, src: int = 0) -> Dict[str, float]:
+    """Broadcast every packed device weight of ``engine`` (both weight sets) from ``src`` in place;
+    the engine keeps pointing at the same buffers."""
+    ts = [t for d in engine._weights for _, t in sorted(d.items())]
+    return broadcast_tensors(ts, src)
+
+
+def max_over_ranks(value: float, device) -> float:
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

@@ -153,6 +153,25 @@ class MVDEngine:
         L.call("mvd_unet_forward", self._h, C.byref(a), _stream())
         return out
 
+    # ------------------------------------------------------------------ measurement
+    PROFILE_CLASSES = {0: "gemm_256x160", 1: "gemm_256x128", 2: "gemm_128x160", 3: "gemm_128x128", 4: "gemm_128x64",
+                       5: "gemm_64x64", 8: "attn_1wave", 9: "attn_2wave", 10: "attn_4wave", 11: "attn_8wave",
+                       16: "groupnorm", 17: "layernorm"}
+
+    def set_profiling(self, enable: bool):
+        L.call("mvd_engine_set_profiling", self._h, int(enable))
+
+    def profile_summary(self):
+        """{class name: dict(launches, ms, flops, bytes)} of the launches recorded since the last call."""
+        cap = 32
+        cls, n_l = (C.c_int * cap)(), (C.c_int * cap)()
+        ms, fl, by = (C.c_double * cap)(), (C.c_double * cap)(), (C.c_double * cap)()
+        n = L.lib().mvd_engine_profile_summary(self._h, cap, cls, n_l, ms, fl, by)
+        if n < 0:
+            raise L.MvdError(f"profile_summary: {L.last_error()}")
+        return {self.PROFILE_CLASSES.get(cls[i], f"class{cls[i]}"): dict(launches=n_l[i], ms=ms[i], flops=fl[i], bytes=by[i])
+                for i in range(n)}
+
     # ------------------------------------------------------------------ introspection (parity tests)
     def features(self) -> Dict[str, torch.Tensor]:
         names = [t[1] for t in self.cfg.transformers()]
