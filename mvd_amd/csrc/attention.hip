@@ -150,14 +150,14 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(const MvdAttnArgs a) {
     for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s1[r]);
     mx = pair_max(mx);
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f((m_run - m_new) * c);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
     const float mc = m_new * c;
     m_run = m_new;
     float psum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      s0[r] = exp2f(fmaf(s0[r], c, -mc));
-      s1[r] = exp2f(fmaf(s1[r], c, -mc));
+      s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], c, -mc));   // raw v_exp_f32: arguments are <= 0
+      s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], c, -mc));
       psum += s0[r] + s1[r];
     }
     l_run = l_run * alpha + psum;

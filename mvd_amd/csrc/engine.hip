@@ -350,8 +350,8 @@ struct UNetPass {
     const int C0 = cfg.block_out_channels[0];
     std::vector<Act> skips;
     Act h = c.new_act(B, H0, W0, C0, true);
-    if (!c.dry && !c.err) CHECK(mvd_launch_conv_in(x_in.p, B, H0, W0, cfg.in_channels, c.WF("conv_in.w", (int64_t)C0 * 9 * cfg.in_channels), c.WF("conv_in.b", C0), C0, h.p, c.s));
-    else { c.WF("conv_in.w", (int64_t)C0 * 9 * cfg.in_channels); c.WF("conv_in.b", C0); }
+    // conv_in: x_in holds im2col rows [B*H*W][64] (k = tap*Cin + ch, zero padded) -> one K=64 MFMA GEMM
+    CHECK(c.linear(x_in.p, nullptr, 64, 0, B * H0 * W0, c.WB("conv_in.w", (int64_t)C0 * 64), c.WF("conv_in.b", C0), C0, nullptr, 0, h.p, C0));
     skips.push_back(h);
     for (int i = 0; i < n; ++i) {
       const int co = cfg.block_out_channels[i];
@@ -608,10 +608,10 @@ int forward_impl(mvd_engine* e, const mvd_forward_args_t& a, hipStream_t s, bool
     const float* tproj = nullptr;
     CHECK(time_path(c, tz, Br, &tproj));
     bf16_t* tx = c.aalloc<bf16_t>((size_t)Br * L * xd);
-    Act xin = c.new_act(Br, H, Wd, cfg.in_channels, true);
+    Act xin = c.new_act(Br, H, Wd, 64, true);   // im2col rows for conv_in
     if (!dry && !c.err) {
       CHECK(mvd_launch_f32_to_bf16(a.encoder_text, (int64_t)Br * L * xd, tx, s));
-      CHECK(mvd_launch_nchw_to_nhwc(a.source_latents, Br, cfg.in_channels, H * Wd, nullptr, nullptr, 0, xin.p, s));
+      CHECK(mvd_launch_im2col_in(a.source_latents, Br, cfg.in_channels, H, Wd, nullptr, nullptr, 0, xin.p, s));
     }
     PassOpts po; po.capture = true; po.ref_batch = Br;
     UNetPass pass{c, cfg, po, Br, H, Wd, L, tx, tproj};
@@ -625,12 +625,12 @@ int forward_impl(mvd_engine* e, const mvd_forward_args_t& a, hipStream_t s, bool
   const float* tproj = nullptr;
   CHECK(time_path(c, a.timesteps, B, &tproj));
   bf16_t* tx = c.aalloc<bf16_t>((size_t)B * L * xd);
-  Act xin = c.new_act(B, H, Wd, cfg.in_channels, true);
+  Act xin = c.new_act(B, H, Wd, 64, true);   // im2col rows for conv_in
   if (!dry && !c.err) {
     CHECK(mvd_launch_f32_to_bf16(a.text, (int64_t)B * L * xd, tx, s));
     const float* sc = nullptr; const float* sh = nullptr;
-    if (use_cam) { sc = film_ss["output"].first; sh = film_ss["output"].second; }   // mvd_unet.py:256-258
-    CHECK(mvd_launch_nchw_to_nhwc(a.sample, B, cfg.in_channels, H * Wd, sc, sh, cfg.in_channels, xin.p, s));
+    if (use_cam) { sc = film_ss["output"].first; sh = film_ss["output"].second; }   // mvd_unet.py:256-258 (input FiLM)
+    CHECK(mvd_launch_im2col_in(a.sample, B, cfg.in_channels, H, Wd, sc, sh, 4, xin.p, s));
   }
   PassOpts po; po.adapter = use_img; po.film = use_cam; po.ref_batch = a.ref_batch; po.film_ss = &film_ss;
   UNetPass pass{c, cfg, po, B, H, Wd, L, tx, tproj};
@@ -665,7 +665,7 @@ int mvd_engine_create(const mvd_config_t* cfg, mvd_engine_t** out) {
     if (c % 64 || c % cfg->norm_num_groups || cfg->num_heads[i] * 64 != c) { mvd_set_error("engine_create: level %d: channels %d must be a multiple of 64/groups with head_dim 64 (heads %d)", i, c, cfg->num_heads[i]); return -1; }
   }
   if (cfg->cross_attention_dim % 64) { mvd_set_error("engine_create: cross_attention_dim must be a multiple of 64"); return -1; }
-  if (cfg->in_channels > 16 || cfg->out_channels > 8) { mvd_set_error("engine_create: in/out channels too large"); return -1; }
+  if (cfg->in_channels > 7 || cfg->out_channels > 8) { mvd_set_error("engine_create: in_channels must be <= 7 (9*Cin <= 64) and out_channels <= 8"); return -1; }
   mvd_engine* e = new mvd_engine();
   e->cfg = *cfg;
   e->feats = enumerate_features(*cfg);

@@ -17,6 +17,7 @@
 //   MFMAs of slab t and written to LDS after them (one barrier per slab).
 // * blockIdx -> tile mapping is XCD-aware: consecutive tiles (same A rows, different N
 //   tile) land on the same XCD so the A slab is fetched from HBM once per XCD L2.
+#include <stdlib.h>
 #include "kernels.h"
 
 namespace {
@@ -40,11 +41,19 @@ struct Cfg {
 
 MVD_DEVINL int swz_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-struct KState {  // position of the next K slab in the (segmented) A operand
-  int seg, tap, cc;
-};
+// AMODE: 0 = dense A (one segment), 1 = implicit 3x3 conv, 2 = conv followed by a dense (1x1 shortcut) segment.
+// The slab cursor (tap / channel offset) lives in scalar registers: it depends on kernel arguments only.
+// GLDS: stage slabs with global_load_lds_dwordx4 (LDS-DMA: no VGPR round trip, no ds_write).  The LDS
+// image is identical to the register-staged one: the DMA writes lane-linear, so the XOR swizzle is applied
+// to the per-lane SOURCE column instead of the LDS address.  Out-of-image conv taps read a 16-byte zero buffer.
+__device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
 
-template <class C>
+MVD_DEVINL void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <class C, int AMODE, bool GLDS>
 __global__ __launch_bounds__(C::NT) void gemm_kernel(const MvdGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -53,20 +62,31 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(const MvdGemmArgs a) {
   const int ntm = (a.M + C::BM - 1) / C::BM;
   const int t = xcd_remap(blockIdx.x, ntn * ntm);
   const int m0 = (t / ntn) * C::BM, n0 = (t % ntn) * C::BN;
-  const int kc = tid & 7;
   const int lrow = tid >> 3;
+  // 16-byte K chunk this thread fetches: register staging swizzles the LDS address, LDS-DMA the source column
+  const int kc = GLDS ? ((tid & 7) ^ ((lrow >> 1) & 7)) : (tid & 7);
+  const int wave_chunk0 = tid & ~63;   // first chunk id of this wave (LDS-DMA destination is wave-uniform)
+
+  constexpr bool HAS_CONV = AMODE != 0;
+  const MvdASeg& cs = a.seg[0];                       // conv segment (AMODE 1, 2)
+  const MvdASeg& ds = a.seg[AMODE == 2 ? 1 : 0];      // dense segment (AMODE 0, 2)
+  const int conv_c = cs.c0, conv_inW = cs.inW, conv_ups = cs.ups;
+  const int limH = conv_ups ? 2 * cs.inH : cs.inH, limW = conv_ups ? 2 * cs.inW : cs.inW;
+  const bf16_t* conv_p = cs.p0;
+  const bf16_t* dp0 = ds.p0;
+  const bf16_t* dp1 = ds.p1;
+  const int dc0 = ds.c0, dc1 = ds.c1;
+  const int nkt_conv = HAS_CONV ? (9 * conv_c) / 64 : 0;
 
   // per-thread A row descriptors
   int a_m[C::A_IT], a_pb[C::A_IT], a_iy[C::A_IT], a_ix[C::A_IT];
-  const bool any_conv = (a.seg[0].mode == MVD_A_CONV3) || (a.nseg > 1 && a.seg[1].mode == MVD_A_CONV3);
 #pragma unroll
   for (int i = 0; i < C::A_IT; ++i) {
     int m = m0 + lrow + i * C::ROWS_PER_IT;
     m = m < a.M ? m : a.M - 1;
     a_m[i] = m;
     a_pb[i] = 0; a_iy[i] = 0; a_ix[i] = 0;
-    if (any_conv) {
-      const MvdASeg& cs = (a.seg[0].mode == MVD_A_CONV3) ? a.seg[0] : a.seg[1];
+    if (HAS_CONV) {
       const int b = m / a.rows_per_batch;
       const int rem = m - b * a.rows_per_batch;
       const int oy = rem / a.outW, ox = rem - oy * a.outW;
@@ -77,50 +97,59 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(const MvdGemmArgs a) {
   }
 
   u32x4 ra[C::A_IT], rb[C::B_IT];
-  KState ks{0, 0, 0};
+  int ld_kt = 0, ld_tap = 0, ld_cc = 0;   // uniform cursor of the next slab to load
 
-  auto load_a = [&]() {
-    const MvdASeg& sg = a.seg[ks.seg];
-    if (sg.mode == MVD_A_DENSE) {
-      const bool first = ks.cc < sg.c0;
-      const bf16_t* base = first ? sg.p0 : sg.p1;
-      const int ld = first ? sg.c0 : sg.c1;
-      const int col = (first ? ks.cc : ks.cc - sg.c0) + kc * 8;
-#pragma unroll
-      for (int i = 0; i < C::A_IT; ++i)
-        ra[i] = *reinterpret_cast<const u32x4*>(base + (size_t)a_m[i] * ld + col);
-    } else {
-      const int dy = ks.tap / 3, dx = ks.tap - dy * 3;
-      const int limH = sg.ups ? 2 * sg.inH : sg.inH, limW = sg.ups ? 2 * sg.inW : sg.inW;
-      const int col = ks.cc + kc * 8;
+  auto load_a = [&](int st) {
+    unsigned char* sa = smem + st * C::STAGE_BYTES;
+    if (HAS_CONV && (AMODE == 1 || ld_kt < nkt_conv)) {
+      const int dy = ld_tap / 3, dx = ld_tap - dy * 3;
+      const int col = ld_cc + kc * 8;
 #pragma unroll
       for (int i = 0; i < C::A_IT; ++i) {
         const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
         const bool ok = (unsigned)iy < (unsigned)limH && (unsigned)ix < (unsigned)limW;
-        const int sy = sg.ups ? (iy >> 1) : iy, sx = sg.ups ? (ix >> 1) : ix;
-        const bf16_t* p = sg.p0 + (size_t)(a_pb[i] + sy * sg.inW + sx) * sg.c0 + col;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (ok) v = *reinterpret_cast<const u32x4*>(p);
-        ra[i] = v;
+        const int sy = conv_ups ? (iy >> 1) : iy, sx = conv_ups ? (ix >> 1) : ix;
+        const bf16_t* p = conv_p + (size_t)(a_pb[i] + sy * conv_inW + sx) * conv_c + col;
+        if (GLDS) {
+          glds16(ok ? (const void*)p : (const void*)g_zero16, sa + (wave_chunk0 + i * C::NT) * 16);
+        } else {
+          u32x4 v = {0u, 0u, 0u, 0u};
+          if (ok) v = *reinterpret_cast<const u32x4*>(p);
+          ra[i] = v;
+        }
       }
+      ld_cc += 64;
+      if (ld_cc >= conv_c) { ld_cc = 0; ++ld_tap; }
+    } else {
+      const bool first = ld_cc < dc0;
+      const bf16_t* base = first ? dp0 : dp1;
+      const int ld = first ? dc0 : dc1;
+      const int col = (first ? ld_cc : ld_cc - dc0) + kc * 8;
+#pragma unroll
+      for (int i = 0; i < C::A_IT; ++i) {
+        const bf16_t* p = base + (size_t)a_m[i] * ld + col;
+        if (GLDS) glds16(p, sa + (wave_chunk0 + i * C::NT) * 16);
+        else ra[i] = *reinterpret_cast<const u32x4*>(p);
+      }
+      ld_cc += 64;
     }
-    // advance to the next slab
-    ks.cc += 64;
-    const int lim = (sg.mode == MVD_A_DENSE) ? sg.c0 + sg.c1 : sg.c0;
-    if (ks.cc >= lim) {
-      ks.cc = 0;
-      if (sg.mode == MVD_A_DENSE || ++ks.tap == 9) { ks.tap = 0; ks.seg++; }
-    }
+    ++ld_kt;
   };
-  auto load_b = [&](int kt) {
+  auto load_b = [&](int kt, int st) {
+    unsigned char* sb = smem + st * C::STAGE_BYTES + C::A_BYTES;
 #pragma unroll
     for (int i = 0; i < C::B_IT; ++i) {
       const int row = lrow + i * C::ROWS_PER_IT;
-      if (C::B_CHUNKS % C::NT == 0 || row < C::BN)
-        rb[i] = *reinterpret_cast<const u32x4*>(a.W + (size_t)(n0 + row) * a.ldw + kt * 64 + kc * 8);
+      if (C::B_CHUNKS % C::NT == 0 || row < C::BN) {
+        const bf16_t* p = a.W + (size_t)(n0 + row) * a.ldw + kt * 64 + kc * 8;
+        if (GLDS) glds16(p, sb + (wave_chunk0 + i * C::NT) * 16);
+        else rb[i] = *reinterpret_cast<const u32x4*>(p);
+      }
     }
   };
   auto store_stage = [&](int st) {
+    if (GLDS) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+    const int kc = tid & 7;
     unsigned char* sa = smem + st * C::STAGE_BYTES;
     unsigned char* sb = sa + C::A_BYTES;
 #pragma unroll
@@ -140,8 +169,8 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(const MvdGemmArgs a) {
     for (int j = 0; j < C::TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nkt = a.Ktot / 64;
-  load_a();
-  load_b(0);
+  load_a(0);
+  load_b(0, 0);
   store_stage(0);
   __syncthreads();
 
@@ -149,7 +178,7 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(const MvdGemmArgs a) {
   for (int kt = 0; kt < nkt; ++kt) {
     const int cur = kt & 1;
     const bool more = kt + 1 < nkt;
-    if (more) { load_a(); load_b(kt + 1); }
+    if (more) { load_a(cur ^ 1); load_b(kt + 1, cur ^ 1); }
     const unsigned char* sa = smem + cur * C::STAGE_BYTES;
     const unsigned char* sb = sa + C::A_BYTES;
 #pragma unroll
@@ -221,20 +250,30 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(const MvdGemmArgs a) {
 
 struct CfgInfo { int bm, bn, tn_even; };
 
-template <class C>
-int launch_cfg(const MvdGemmArgs& a, hipStream_t s) {
+template <class C, int AMODE, bool GLDS>
+int launch_mode(const MvdGemmArgs& a, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<C>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<C, AMODE, GLDS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     if (e != hipSuccess) { mvd_set_error("gemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return -2; }
     attr_set = true;
   }
   const int ntm = (a.M + C::BM - 1) / C::BM, ntn = a.N / C::BN;
-  hipLaunchKernelGGL(gemm_kernel<C>, dim3(ntm * ntn), dim3(C::NT), C::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((gemm_kernel<C, AMODE, GLDS>), dim3(ntm * ntn), dim3(C::NT), C::LDS_BYTES, s, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { mvd_set_error("gemm launch: %s", hipGetErrorString(e)); return -3; }
   return 0;
+}
+
+template <class C>
+int launch_cfg(const MvdGemmArgs& a, hipStream_t s, bool glds) {
+  if (glds) {
+    if (a.seg[0].mode == MVD_A_DENSE) return launch_mode<C, 0, true>(a, s);
+    return a.nseg == 1 ? launch_mode<C, 1, true>(a, s) : launch_mode<C, 2, true>(a, s);
+  }
+  if (a.seg[0].mode == MVD_A_DENSE) return launch_mode<C, 0, false>(a, s);
+  return a.nseg == 1 ? launch_mode<C, 1, false>(a, s) : launch_mode<C, 2, false>(a, s);
 }
 
 using C0 = Cfg<256, 160, 4, 2>;
@@ -250,15 +289,18 @@ constexpr int kNumCfgs = 6;
 
 extern "C" int mvd_gemm_num_configs(void) { return kNumCfgs; }
 
-// largest tile that still yields >= ~2 blocks per CU; otherwise the config with most blocks
+// Tile choice (tools/tune_gemm.py sweep on MI355X, profiles/r01_tune_gemm_B32.log): 128x160 (4 waves, two
+// co-resident workgroups per CU) beats the 256-row tiles on every shape of the forward; fall to smaller tiles
+// until the grid has >= ~300 workgroups, else take the config with the most workgroups.
 int mvd_gemm_pick_config(const MvdGemmArgs& a) {
+  static const int order[] = {2, 3, 4, 5};
   int cfg = -1;
   long best_blocks = -1;
-  for (int c = 0; c < kNumCfgs; ++c) {
+  for (int c : order) {
     if (a.N % kCfgs[c].bn) continue;
     if (a.geglu && !kCfgs[c].tn_even) continue;
     const long blocks = (long)((a.M + kCfgs[c].bm - 1) / kCfgs[c].bm) * (a.N / kCfgs[c].bn);
-    if (blocks >= 480) return c;
+    if (blocks >= 300) return c;
     if (blocks > best_blocks) { best_blocks = blocks; cfg = c; }
   }
   return cfg;
@@ -280,7 +322,7 @@ int mvd_launch_gemm(const MvdGemmArgs& a, hipStream_t s, int force_cfg) {
     } else { mvd_set_error("gemm: bad mode"); return -1; }
     ksum += g.ksize;
   }
-  if (a.nseg == 2 && a.seg[0].mode == MVD_A_CONV3 && a.seg[1].mode == MVD_A_CONV3) { mvd_set_error("gemm: two conv segments unsupported"); return -1; }
+  if (a.nseg == 2 && !(a.seg[0].mode == MVD_A_CONV3 && a.seg[1].mode == MVD_A_DENSE)) { mvd_set_error("gemm: a second segment must be a dense segment after a conv segment"); return -1; }
   if (ksum != a.Ktot) { mvd_set_error("gemm: segment K sum %d != Ktot %d", ksum, a.Ktot); return -1; }
   if (a.ldw < a.Ktot || (a.ldw % 8) || !a.W) { mvd_set_error("gemm: bad weight stride ldw=%d (K=%d)", a.ldw, a.Ktot); return -1; }
   if (a.rows_per_batch <= 0) { mvd_set_error("gemm: rows_per_batch must be > 0"); return -1; }
@@ -289,15 +331,19 @@ int mvd_launch_gemm(const MvdGemmArgs& a, hipStream_t s, int force_cfg) {
   const int on = a.geglu ? a.N / 2 : a.N;
   if (a.ldo < on || (a.ldo % 4) || (a.res && (a.ldres % 4))) { mvd_set_error("gemm: bad leading dims"); return -1; }
 
+  // force_cfg: -1 = heuristic; 0..5 = tile config with register staging; 8..13 = same tiles with LDS-DMA staging
+  static const int default_glds = [] { const char* e = getenv("MVD_GEMM_GLDS"); return e ? atoi(e) : 1; }();
+  bool glds = default_glds != 0;
   int cfg = force_cfg;
+  if (cfg >= 8) { glds = true; cfg -= 8; } else if (cfg >= 0) { glds = false; }
   if (cfg < 0) cfg = mvd_gemm_pick_config(a);
   if (cfg < 0 || cfg >= kNumCfgs || a.N % kCfgs[cfg].bn || (a.geglu && !kCfgs[cfg].tn_even)) { mvd_set_error("gemm: no tile config for N=%d geglu=%d cfg=%d", a.N, a.geglu, cfg); return -1; }
   switch (cfg) {
-    case 0: return launch_cfg<C0>(a, s);
-    case 1: return launch_cfg<C1>(a, s);
-    case 2: return launch_cfg<C2>(a, s);
-    case 3: return launch_cfg<C3>(a, s);
-    case 4: return launch_cfg<C4>(a, s);
-    default: return launch_cfg<C5>(a, s);
+    case 0: return launch_cfg<C0>(a, s, glds);
+    case 1: return launch_cfg<C1>(a, s, glds);
+    case 2: return launch_cfg<C2>(a, s, glds);
+    case 3: return launch_cfg<C3>(a, s, glds);
+    case 4: return launch_cfg<C4>(a, s, glds);
+    default: return launch_cfg<C5>(a, s, glds);
   }
 }

@@ -82,6 +82,9 @@ int mvd_launch_conv_in(const bf16_t* x, int batch, int h, int w, int cin, const 
 // conv_out: 3x3 pad 1, C -> tiny Cout (<=8), NHWC bf16 in, NCHW fp32 out, weights bf16 [Cout][3][3][C]
 int mvd_launch_conv_out(const bf16_t* x, int batch, int h, int w, int c, const bf16_t* wt, const float* bias,
                         int cout, float* y, hipStream_t s);
+// conv_in as a GEMM: NCHW fp32 (+FiLM) -> im2col [batch*h*w][64] bf16, k = tap*c + ch, zero padded (c <= 7)
+int mvd_launch_im2col_in(const float* x, int batch, int c, int h, int w, const float* scale, const float* shift, int ld_ss,
+                         bf16_t* y, hipStream_t s);
 // fp32 -> bf16 copy
 int mvd_launch_f32_to_bf16(const float* x, int64_t n, bf16_t* y, hipStream_t s);
 int mvd_launch_nhwc_to_nchw_f32(const bf16_t* x, int batch, int hw, int c, float* y, hipStream_t s);

@@ -219,6 +219,41 @@ __global__ void film_params_kernel(const float* __restrict__ raw, int dim, float
   shift[i] = t * strength;
 }
 
+// conv_in front end: NCHW fp32 latent (+ optional camera FiLM) -> im2col rows [pixel][64] bf16 with
+// k = tap*C + ch (tap-major, like the packed conv weights), zero padded to 64, so conv_in runs as a K=64
+// MFMA GEMM instead of a scalar convolution.
+template <int CIN>
+__global__ void im2col_in_kernel(const float* __restrict__ x, int h, int w, const float* __restrict__ scale,
+                                 const float* __restrict__ shift, int ld_ss, bf16_t* __restrict__ y, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // pixel index over (b, y, x)
+  if (i >= total) return;
+  const int hw = h * w;
+  const int p = i % hw;
+  const int b = i / hw;
+  const int oy = p / w, ox = p % w;
+  float v[64];
+#pragma unroll
+  for (int k = 0; k < 64; ++k) v[k] = 0.f;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+    const bool ok = (unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w;
+#pragma unroll
+    for (int ch = 0; ch < CIN; ++ch) {
+      if (ok) {
+        float t = x[((size_t)b * CIN + ch) * hw + iy * w + ix];
+        if (scale) t = t * scale[(size_t)b * ld_ss + ch] + shift[(size_t)b * ld_ss + ch];
+        v[tap * CIN + ch] = t;
+      }
+    }
+  }
+  u32x4* out = reinterpret_cast<u32x4*>(y + i * 64);
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+    out[q] = u32x4{pack2bf(v[8 * q], v[8 * q + 1]), pack2bf(v[8 * q + 2], v[8 * q + 3]), pack2bf(v[8 * q + 4], v[8 * q + 5]),
+                   pack2bf(v[8 * q + 6], v[8 * q + 7])};
+}
+
 __global__ void film_nchw_f32_kernel(const float* __restrict__ x, int c, int hw, const float* __restrict__ scale,
                                      const float* __restrict__ shift, float* __restrict__ y, long total) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -319,4 +354,21 @@ int mvd_launch_film_nchw_f32(const float* x, int batch, int c, int hw, const flo
   const long total = (long)batch * c * hw;
   hipLaunchKernelGGL(film_nchw_f32_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, x, c, hw, scale, shift, y, total);
   return check("film_nchw");
+}
+
+int mvd_launch_im2col_in(const float* x, int batch, int c, int h, int w, const float* scale, const float* shift, int ld_ss,
+                         bf16_t* y, hipStream_t s) {
+  if (!x || !y || batch <= 0 || c <= 0 || c > 7 || h <= 0 || w <= 0 || ((scale == nullptr) != (shift == nullptr))) { mvd_set_error("im2col_in: bad arguments (c=%d must be <= 7)", c); return -1; }
+  const long total = (long)batch * h * w;
+  const dim3 g(nblk(total, 128)), t(128);
+  switch (c) {
+    case 1: hipLaunchKernelGGL(im2col_in_kernel<1>, g, t, 0, s, x, h, w, scale, shift, ld_ss, y, total); break;
+    case 2: hipLaunchKernelGGL(im2col_in_kernel<2>, g, t, 0, s, x, h, w, scale, shift, ld_ss, y, total); break;
+    case 3: hipLaunchKernelGGL(im2col_in_kernel<3>, g, t, 0, s, x, h, w, scale, shift, ld_ss, y, total); break;
+    case 4: hipLaunchKernelGGL(im2col_in_kernel<4>, g, t, 0, s, x, h, w, scale, shift, ld_ss, y, total); break;
+    case 5: hipLaunchKernelGGL(im2col_in_kernel<5>, g, t, 0, s, x, h, w, scale, shift, ld_ss, y, total); break;
+    case 6: hipLaunchKernelGGL(im2col_in_kernel<6>, g, t, 0, s, x, h, w, scale, shift, ld_ss, y, total); break;
+    default: hipLaunchKernelGGL(im2col_in_kernel<7>, g, t, 0, s, x, h, w, scale, shift, ld_ss, y, total); break;
+  }
+  return check("im2col_in");
 }

@@ -47,7 +47,8 @@ def _geglu_rows(w: torch.Tensor) -> torch.Tensor:
 def pack_unet(sd: Dict[str, torch.Tensor], cfg: UNetConfig, device, adapter: bool, ref_scale: float = 0.0) -> Dict[str, torch.Tensor]:
     """``sd`` holds diffusers keys (no wrapper prefix) and, when ``adapter``, the ``...processor.*`` keys."""
     out: Dict[str, torch.Tensor] = {}
-    out["conv_in.w"] = _f32(_conv_w(sd["conv_in.weight"]), device)
+    w_in = _conv_w(sd["conv_in.weight"])                       # [C0][9*Cin] -> zero padded to K = 64 (one MFMA slab)
+    out["conv_in.w"] = _bf(torch.nn.functional.pad(w_in, (0, 64 - w_in.shape[1])), device)
     out["conv_in.b"] = _f32(sd["conv_in.bias"], device)
     out["time.l1.w"] = _bf(sd["time_embedding.linear_1.weight"], device)
     out["time.l1.b"] = _f32(sd["time_embedding.linear_1.bias"], device)

@@ -36,11 +36,12 @@ def close(got, want, tol=2 ** -7, what=""):
 
 
 # ------------------------------------------------------------------------------- GEMM
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4, 5])
+# tile configs 0..5 use register staging, 8..13 the same tiles with LDS-DMA (global_load_lds) staging
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4, 5, 8, 9, 10, 11, 12, 13])
 @pytest.mark.parametrize("m,n,k", [(300, 640, 320), (1024, 1280, 192), (77, 640, 1024), (5, 1920, 64)])
 def test_linear_configs(ops, cfg, m, n, k):
     tiles = {0: 160, 1: 128, 2: 160, 3: 128, 4: 64, 5: 64}
-    if cfg >= 0 and n % tiles[cfg]:
+    if cfg >= 0 and n % tiles[cfg % 8]:
         pytest.skip("N not divisible by this tile")
     a, w = rnd(m, k, seed=1), rnd(n, k, scale=1 / math.sqrt(k), seed=2)
     bias = rnd(n, seed=3, dtype=torch.float32)
@@ -64,7 +65,7 @@ def test_linear_epilogues(ops):
     close(got32, a.float() @ w[:, :k1].float().T + bias, tol=1e-4, what="linear fp32 out")
 
 
-@pytest.mark.parametrize("cfg", [-1, 1, 3, 4, 5])
+@pytest.mark.parametrize("cfg", [-1, 1, 3, 4, 5, 9, 11, 12, 13])
 def test_linear_geglu(ops, cfg):
     from mvd_amd.packing import _geglu_rows
     m, c = 200, 128
@@ -85,9 +86,10 @@ def _pack(w):
     return w.float().permute(0, 2, 3, 1).reshape(co, -1).to(torch.bfloat16)
 
 
+@pytest.mark.parametrize("cfg", [-1, 5, 13])
 @pytest.mark.parametrize("stride,ups", [(1, False), (2, False), (1, True)])
 @pytest.mark.parametrize("B,H,W,cin,cout", [(2, 16, 16, 64, 128), (1, 8, 12, 192, 64), (3, 6, 6, 128, 320)])
-def test_conv3x3(ops, stride, ups, B, H, W, cin, cout):
+def test_conv3x3(ops, stride, ups, B, H, W, cin, cout, cfg):
     x = rnd(B, cin, H, W, seed=1)
     w = rnd(cout, cin, 3, 3, scale=1 / math.sqrt(9 * cin), seed=2)
     bias = rnd(cout, seed=3, dtype=torch.float32)
@@ -95,11 +97,12 @@ def test_conv3x3(ops, stride, ups, B, H, W, cin, cout):
     if ups:
         xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
     want = F.conv2d(xin, w.float(), bias, stride=stride, padding=1).permute(0, 2, 3, 1)
-    got = ops.conv3x3(x.permute(0, 2, 3, 1).contiguous().cuda(), _pack(w).cuda(), bias.cuda(), stride=stride, upsample=ups)
+    got = ops.conv3x3(x.permute(0, 2, 3, 1).contiguous().cuda(), _pack(w).cuda(), bias.cuda(), stride=stride, upsample=ups,
+                      force_cfg=cfg)
     close(got, want, what=f"conv3x3 s{stride} ups{ups}")
 
 
-@pytest.mark.parametrize("cfg", [-1, 0, 2, 4, 5])
+@pytest.mark.parametrize("cfg", [-1, 0, 2, 4, 5, 8, 10, 12, 13])
 def test_conv3x3_resnet_fusions(ops, cfg):
     """conv1 (+time-embedding row vector) and conv2 (+1x1 shortcut over a 2-source concat / + residual)."""
     B, H, W, c0, c1, cout = 2, 8, 8, 128, 64, 320
