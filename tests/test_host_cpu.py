@@ -1,0 +1,151 @@
+"""Host-side logic that needs no GPU: state-dict compatibility with the reference's key schema,
+weight packing layouts, adapter initialisation (golden G3), loud failure without a GPU."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import fixture_gen as FG
+from mvd_amd.config import UNetConfig
+from mvd_amd.mvd_unet import MultiViewUNet, UNetOutput
+from mvd_amd.packing import _geglu_rows, pack_unet
+from oracle import mvd as OM
+from oracle import sd21_unet as OU
+
+
+@pytest.fixture(scope="module")
+def tiny_model():
+    cfg = OU.UNetConfig.tiny()
+    params = OM.init_mvd_params(cfg, 0, cam_dim=96, cam_hidden=48)
+    m = MultiViewUNet(None, unet_config=UNetConfig.tiny(), init="empty", cam_output_dim=96, cam_hidden_dim=48)
+    return cfg, params, m
+
+
+def test_state_dict_schema_matches_reference_keys(tiny_model):
+    cfg, params, m = tiny_model
+    sd = m.state_dict()
+    assert set(sd) == set(params)
+    assert all(sd[k].shape == params[k].shape for k in sd)
+    res = m.load_state_dict(params, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    # prefixes / names the reference relies on (infer.py:46-69, training.py:70-76)
+    assert "base_unet.down_blocks.0.attentions.0.transformer_blocks.0.attn1.processor.to_q_ref.weight" in sd
+    assert "camera_encoder.modulators.mid.3.weight" in sd and "image_encoder.unet.conv_in.weight" in sd
+    procs = [n for n, _ in m.base_unet.named_modules() if n.endswith(".processor")]
+    assert len(procs) == 32
+    assert UNetOutput(sample=torch.zeros(1)).sample.shape == (1,)
+
+
+def test_sd21_mirror_parameter_counts():
+    """Without allocating: meta-device build reproduces SD2.1's 865,910,724 + 99,198,080 + 19,062,536."""
+    with torch.device("meta"):
+        m = MultiViewUNet(None, unet_config=UNetConfig.sd21(), init="default")
+    n = lambda mod: sum(p.numel() for p in mod.parameters())  # noqa: E731
+    n_base = sum(p.numel() for k, p in m.base_unet.named_parameters() if ".processor." not in k)
+    n_ad = sum(p.numel() for k, p in m.base_unet.named_parameters() if ".processor." in k)
+    assert n_base == 865_910_724 and n_ad == 99_198_080
+    assert n(m.camera_encoder) == 19_062_536 and n(m.image_encoder) == 865_910_724
+
+
+def test_feature_to_attention_map_and_attrs(tiny_model):
+    _, _, m = tiny_model
+    assert len(m.feature_to_attention_map) == 16 and len(m.attention_layer_map) == 32
+    assert m.feature_to_attention_map["up_block_3_attn_2"] == ["up_block_3_attn_2_self", "up_block_3_attn_2_cross"]
+    assert m.config.sample_size == 16 and m.use_camera_conditioning and m.use_image_conditioning
+    assert list(m.camera_encoder.modulation_hidden_dims) == ["down_0", "down_1", "down_2", "down_3", "up_0", "up_1",
+                                                              "up_2", "up_3", "mid", "output"]
+
+
+def test_forward_on_cpu_fails_loudly(tiny_model):
+    """No CPU fallback: the product path refuses to run without the HIP engine / a GPU."""
+    from mvd_amd._lib import MvdError
+    _, _, m = tiny_model
+    with pytest.raises(MvdError):
+        m(torch.zeros(1, 4, 16, 16), torch.tensor(1), torch.zeros(1, 7, 128))
+    with pytest.raises(MvdError):
+        m.camera_encoder.encode_cameras(torch.eye(4)[None], torch.eye(4)[None])
+
+
+def test_product_never_imports_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dirpath, _, files in os.walk(os.path.join(root, "mvd_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_geglu_row_interleave():
+    w = torch.arange(64 * 3, dtype=torch.float32).reshape(64, 3)
+    p = _geglu_rows(w)
+    assert torch.equal(p[:16], w[:16]) and torch.equal(p[16:32], w[32:48])
+    assert torch.equal(p[32:48], w[16:32]) and torch.equal(p[48:], w[48:])
+
+
+def test_packing_layouts(tiny_model):
+    cfg, params, _ = tiny_model
+    sd = OM._sub(params, "base_unet.")
+    packed = pack_unet(sd, UNetConfig.tiny(), "cpu", adapter=True, ref_scale=0.3)
+    C = 64
+    k = "down_blocks.0.attentions.0"
+    b = f"{k}.transformer_blocks.0"
+    assert packed[f"{k}.attn1.qkv.w"].shape == (4 * C, C)
+    torch.testing.assert_close(packed[f"{k}.attn1.qkv.w"][3 * C:].float(),
+                               sd[f"{b}.attn1.processor.to_q_ref.weight"].to(torch.bfloat16).float())
+    wo = packed[f"{k}.attn2.out.w"]
+    assert wo.shape == (C, 2 * C)
+    torch.testing.assert_close(wo[:, C:].float(), (0.3 * sd[f"{b}.attn2.processor.to_out_ref.0.weight"]).to(torch.bfloat16).float())
+    torch.testing.assert_close(packed[f"{k}.attn2.out.b"], sd[f"{b}.attn2.to_out.0.bias"] + 0.3 * sd[f"{b}.attn2.processor.to_out_ref.0.bias"])
+    torch.testing.assert_close(packed[f"{k}.attn2.out.b0"], sd[f"{b}.attn2.to_out.0.bias"])
+    assert packed[f"{k}.ref_kv.w"].shape == (4 * C, C) and packed[f"{k}.attn2.kv.w"].shape == (2 * C, 128)
+    # conv: [Cout][ky][kx][Cin]; resnet conv2 carries the 1x1 shortcut along K; conv_in padded to one K slab
+    r = "down_blocks.1.resnets.0"
+    w2 = packed[f"{r}.conv2.w"]
+    assert w2.shape == (128, 9 * 128 + 64)
+    torch.testing.assert_close(w2[:, 9 * 128:].float(), sd[f"{r}.conv_shortcut.weight"].reshape(128, 64).to(torch.bfloat16).float())
+    torch.testing.assert_close(w2[5, 128 * 4:128 * 5].float(), sd[f"{r}.conv2.weight"][5, :, 1, 1].to(torch.bfloat16).float())
+    assert packed["conv_in.w"].shape == (64, 64) and (packed["conv_in.w"][:, 36:] == 0).all()
+    total = sum(co for _, _, co in UNetConfig.tiny().resnets())
+    assert packed["temb_proj.w"].shape == (total, 256) and total % 64 == 0
+
+
+@pytest.mark.parametrize("C", [64, 96, 128])
+@pytest.mark.parametrize("kind", ["self", "cross"])
+def test_g3_load_original_weights_mirror(golden_dir, C, kind):
+    """mvd_amd.attention.get_attention_processor_for_module reproduces the reference's initialisation."""
+    from types import SimpleNamespace
+    from mvd_amd.attention import get_attention_processor_for_module
+    g = np.load(os.path.join(golden_dir, "g3_load_original_weights.npz"))
+    kdim = C if kind == "self" else 96
+    tag = f"g3.{C}.{kind}"
+    attn = SimpleNamespace(heads=C // 32, processor=object())
+    attn.to_q = torch.nn.Linear(C, C, bias=False)
+    attn.to_k = torch.nn.Linear(kdim, C, bias=False)
+    attn.to_v = torch.nn.Linear(kdim, C, bias=False)
+    attn.to_out = torch.nn.ModuleList([torch.nn.Linear(C, C)])
+    with torch.no_grad():
+        attn.to_q.weight.copy_(FG.fx_linear(f"{tag}.q", C, C))
+        attn.to_k.weight.copy_(FG.fx_linear(f"{tag}.k", C, kdim))
+        attn.to_v.weight.copy_(FG.fx_linear(f"{tag}.v", C, kdim))
+        attn.to_out[0].weight.copy_(FG.fx_linear(f"{tag}.o", C, C))
+        attn.to_out[0].bias.copy_(FG.fx(f"{tag}.ob", (C,), 0.1))
+    proc = get_attention_processor_for_module("n", attn, img_ref_scale=0.25)
+    assert proc.original_processor is attn.processor and proc.dim_head == 32 and proc.ref_scale_val == 0.25
+    for k, v in proc.state_dict().items():
+        if "ref_ln" not in k:
+            torch.testing.assert_close(v, torch.from_numpy(g[f"{C}.{kind}.{k}"]), rtol=0, atol=1e-6)
+
+
+def test_camera_relative_transform_mirror(golden_dir):
+    from mvd_amd.camera_encoder import CameraEncoder
+    g = np.load(os.path.join(golden_dir, "g2_camera_encoder.npz"))
+    enc = CameraEncoder(output_dim=96, hidden_dim=48, modulation_hidden_dims={"down_0": 64})
+    src, tgt = FG.g2_cameras(3)
+    rel = enc.compute_relative_transform(src, tgt)
+    torch.testing.assert_close(rel["R"], torch.from_numpy(g["small.R"]), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(rel["T"], torch.from_numpy(g["small.T"]), rtol=1e-6, atol=1e-6)
+    last = enc.modulators["down_0"][-1]
+    assert torch.all(last.bias[:64] == 0.5) and torch.all(last.bias[64:] == 0)      # camera_encoder.py:93-105
+    assert enc.pos_enc_dim == 16 and enc.draw_projection("cpu").shape == (96, 96)
