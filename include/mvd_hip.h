@@ -119,11 +119,12 @@ int mvd_engine_get_camera_embedding(mvd_engine_t* e, float* out, void* stream);
 /* out[M][N] = alpha*(A[M][K] . W[N][K]^T + bias + rowvec[m/rows_per_batch]) + res ; bf16 A/W/res */
 int mvd_op_linear(const void* a, const void* a2, int k1, int k2, const void* w, const float* bias, const float* rowvec,
                   int ld_rowvec, int rows_per_batch, const void* res, float alpha, int geglu, void* out, int out_f32,
-                  int m, int n, int force_cfg, void* stream);
+                  int m, int n, int force_cfg, int splitk, float* splitk_ws /* splitk*m*n floats when splitk > 1 */,
+                  void* stream);
 /* 3x3 conv (pad 1) on NHWC bf16 as implicit GEMM; optional fused 1x1 shortcut on (sc, sc2) */
 int mvd_op_conv3x3(const void* x, int batch, int in_h, int in_w, int cin, int stride, int upsample, const void* w,
                    const float* bias, const float* rowvec, int ld_rowvec, const void* res, const void* sc, const void* sc2,
-                   int sc_c1, int sc_c2, void* out, int cout, int force_cfg, void* stream);
+                   int sc_c1, int sc_c2, void* out, int cout, int force_cfg, int splitk, float* splitk_ws, void* stream);
 int mvd_op_attention(const void* q, const void* k, const void* v, void* o, int batch, int heads, int nq, int nk, int ldq,
                      int ldk, int ldv, int ldo, float scale, void* stream);
 int mvd_op_groupnorm(const void* x0, const void* x1, int c0, int c1, int batch, int hw, int groups, float eps,

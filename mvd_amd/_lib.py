@@ -59,10 +59,10 @@ _SIGS = {
     "mvd_engine_get_camera_embedding": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mvd_op_linear": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                 C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
-                                C.c_void_p]),
+                                C.c_int, C.c_void_p, C.c_void_p]),
     "mvd_op_conv3x3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
-                                 C.c_int, C.c_int, C.c_void_p]),
+                                 C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mvd_op_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "mvd_op_groupnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,

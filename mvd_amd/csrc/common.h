@@ -26,8 +26,21 @@ MVD_DEVINL unsigned int pack2bf(float lo, float hi) {
 MVD_DEVINL float bflo(unsigned int u) { return __builtin_bit_cast(float, u << 16); }
 MVD_DEVINL float bfhi(unsigned int u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 
-MVD_DEVINL float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-MVD_DEVINL float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+MVD_DEVINL float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+// exact-erf GELU with erf from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below bf16 resolution):
+// ~14 VALU ops instead of the ~40 of libm erff -- the GEGLU epilogue is on the FF1 GEMM's critical path.
+MVD_DEVINL float gelu_erf_f(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  p *= t;
+  const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
+  const float erf_abs = fmaf(-p, e, 1.0f);
+  return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
 
 MVD_DEVINL float wave_sum(float v) {
 #pragma unroll

@@ -7,6 +7,8 @@
 // attention.py:48-188 (adapter branch), camera_encoder.py:160-255 (embedding + FiLM) and
 // the diffusers-0.32.2 UNet2DConditionModel layer order.
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -61,6 +63,8 @@ struct mvd_engine {
   float* cam_emb = nullptr; int cam_batch = 0;
   std::vector<int> temb_off;        // per resnet offset into the fused time_emb_proj output
   int temb_total = 0;
+  std::vector<int> tkv_off;         // per transformer column offset into the fused text K/V projection
+  int tkv_total = 0;
   // optional per-kernel-class profiling (HIP events on the launch stream)
   bool prof = false;
   struct ProfRec { int cls; double flops; double bytes; hipEvent_t e0, e1; };
@@ -122,9 +126,21 @@ struct Ctx {
     return r;
   }
   int gemm(MvdGemmArgs& g) {
-    if (err) return err; if (dry) return 0;
-    const double fl = 2.0 * g.M * (double)g.N * g.Ktot;
-    return profiled(e->prof ? mvd_gemm_pick_config(g) : 0, fl, 0.0, [&] { return mvd_launch_gemm(g, s); });
+    if (err) return err;
+    // split-K for tile grids that cannot fill the chip: fp32 partials in scoped workspace + a reduce/epilogue pass
+    const int S = mvd_gemm_pick_splitk(g);
+    const size_t mark = e->tmp.off;
+    if (S > 1) { g.splitk = S; g.part = talloc<float>((size_t)S * g.M * g.N); }
+    static const bool trace = getenv("MVD_TRACE_GEMM") != nullptr;
+    if (trace && !dry) fprintf(stderr, "gemm M=%d N=%d K=%d mode=%d nseg=%d geglu=%d cfg=%d splitk=%d\n", g.M, g.N, g.Ktot, g.seg[0].mode, g.nseg, g.geglu, mvd_gemm_pick_config(g), S);
+    int r = 0;
+    if (!dry) {
+      const double fl = 2.0 * g.M * (double)g.N * g.Ktot;
+      r = profiled(e->prof ? mvd_gemm_pick_config(g) : 0, fl, 0.0, [&] { return mvd_launch_gemm(g, s); });
+      if (!r && S > 1) r = mvd_launch_splitk_reduce(g, s);
+    }
+    e->tmp.off = mark;
+    return r;
   }
 
   // dense linear: out[M][N] = alpha*(A.W^T + bias) + res
@@ -231,6 +247,7 @@ struct UNetPass {
   int B, H0, W0, L;
   const bf16_t* text;      // [B*L][xdim] bf16
   const float* tproj;      // [B][temb_total] fp32 (all time_emb_proj outputs incl. bias)
+  bf16_t* tkv = nullptr;   // [B*L][tkv_total] bf16: text K/V of every attn2 site (one GEMM per pass)
   int resnet_idx = 0;
   int feat_idx = 0;
 
@@ -301,13 +318,13 @@ struct UNetPass {
     {
       const int nq = ad ? 2 * C : C;
       bf16_t* q2 = c.talloc<bf16_t>((size_t)M * nq);
-      bf16_t* kv2 = c.talloc<bf16_t>((size_t)B_ * L * 2 * C);
+      const bf16_t* kv2 = tkv + c.e->tkv_off[feat_idx];   // [B*L][2C] slice of the fused text K/V
+      const int ldkv = c.e->tkv_total;
       CHECK(c.layernorm(h, M, C, c.WF(key + ".ln2.g", C), c.WF(key + ".ln2.b", C), ln));
       CHECK(c.linear(ln, nullptr, C, 0, M, c.WB(key + ".attn2.q.w", (int64_t)(packed ? 2 : 1) * C * C), nullptr, nq, nullptr, 0, q2, nq));
-      CHECK(c.linear(text, nullptr, xd, 0, B_ * L, c.WB(key + ".attn2.kv.w", (int64_t)2 * C * xd), nullptr, 2 * C, nullptr, 0, kv2, 2 * C));
       MvdAttnArgs a; memset(&a, 0, sizeof(a));
       a.batch = B_; a.heads = heads; a.scale = scale; a.nprob = ad ? 2 : 1;
-      a.p[0] = {q2, kv2, kv2 + C, o_self, nq, 2 * C, 2 * C, C, (int64_t)hw * nq, (int64_t)L * 2 * C, (int64_t)L * 2 * C, (int64_t)hw * C, hw, L};
+      a.p[0] = {q2, kv2, kv2 + C, o_self, nq, ldkv, ldkv, C, (int64_t)hw * nq, (int64_t)L * ldkv, (int64_t)L * ldkv, (int64_t)hw * C, hw, L};
       if (ad) a.p[1] = {q2 + C, rkv + 2 * C, rkv + 3 * C, o_ref, nq, 4 * C, 4 * C, C, (int64_t)hw * nq, (int64_t)ref_nk * 4 * C, (int64_t)ref_nk * 4 * C, (int64_t)hw * C, hw, ref_nk};
       CHECK(c.attention(a));
       const int kout = ad ? 2 * C : C;
@@ -349,6 +366,10 @@ struct UNetPass {
     const int n = cfg.num_levels, Lb = cfg.layers_per_block;
     const int C0 = cfg.block_out_channels[0];
     std::vector<Act> skips;
+    // text K/V for all attn2 sites of this pass: one [B*L][xdim] x [tkv_total][xdim]^T GEMM instead of 16 small ones
+    tkv = c.aalloc<bf16_t>((size_t)B * L * c.e->tkv_total);
+    CHECK(c.linear(text, nullptr, cfg.cross_attention_dim, 0, B * L, c.WB("text_kv.w", (int64_t)c.e->tkv_total * cfg.cross_attention_dim), nullptr,
+                   c.e->tkv_total, nullptr, 0, tkv, c.e->tkv_total));
     Act h = c.new_act(B, H0, W0, C0, true);
     // conv_in: x_in holds im2col rows [B*H*W][64] (k = tap*Cin + ch, zero padded) -> one K=64 MFMA GEMM
     CHECK(c.linear(x_in.p, nullptr, 64, 0, B * H0 * W0, c.WB("conv_in.w", (int64_t)C0 * 64), c.WF("conv_in.b", C0), C0, nullptr, 0, h.p, C0));
@@ -672,6 +693,9 @@ int mvd_engine_create(const mvd_config_t* cfg, mvd_engine_t** out) {
   int off = 0;
   for (auto& r : enumerate_resnets(*cfg)) { e->temb_off.push_back(off); off += r.cout; }
   e->temb_total = off;
+  off = 0;
+  for (auto& f : e->feats) { e->tkv_off.push_back(off); off += 2 * f.C; }
+  e->tkv_total = off;
   *out = e;
   return 0;
 }
@@ -825,7 +849,7 @@ int mvd_engine_get_camera_embedding(mvd_engine_t* e, float* out, void* stream) {
 // ------------------------------------------------------------------ operator-level entry points
 int mvd_op_linear(const void* a, const void* a2, int k1, int k2, const void* w, const float* bias, const float* rowvec,
                   int ld_rowvec, int rows_per_batch, const void* res, float alpha, int geglu, void* out, int out_f32, int m,
-                  int n, int force_cfg, void* stream) {
+                  int n, int force_cfg, int splitk, float* splitk_ws, void* stream) {
   MvdGemmArgs g; memset(&g, 0, sizeof(g));
   g.seg[0].p0 = (const bf16_t*)a; g.seg[0].p1 = (const bf16_t*)a2; g.seg[0].c0 = k1; g.seg[0].c1 = k2;
   g.seg[0].mode = MVD_A_DENSE; g.seg[0].ksize = k1 + k2; g.nseg = 1;
@@ -834,12 +858,17 @@ int mvd_op_linear(const void* a, const void* a2, int k1, int k2, const void* w, 
   g.bias = bias; g.rowvec = rowvec; g.ld_rowvec = ld_rowvec; g.res = (const bf16_t*)res;
   const int on = geglu ? n / 2 : n;
   g.ldres = on; g.alpha = alpha; g.geglu = geglu; g.out = out; g.ldo = on; g.out_f32 = out_f32;
+  if (splitk > 1) {
+    g.splitk = splitk; g.part = splitk_ws;
+    if (int r = mvd_launch_gemm(g, (hipStream_t)stream, force_cfg)) return r;
+    return mvd_launch_splitk_reduce(g, (hipStream_t)stream);
+  }
   return mvd_launch_gemm(g, (hipStream_t)stream, force_cfg);
 }
 
 int mvd_op_conv3x3(const void* x, int batch, int in_h, int in_w, int cin, int stride, int upsample, const void* w,
                    const float* bias, const float* rowvec, int ld_rowvec, const void* res, const void* sc, const void* sc2,
-                   int sc_c1, int sc_c2, void* out, int cout, int force_cfg, void* stream) {
+                   int sc_c1, int sc_c2, void* out, int cout, int force_cfg, int splitk, float* splitk_ws, void* stream) {
   MvdGemmArgs g; memset(&g, 0, sizeof(g));
   const int oh = upsample ? in_h * 2 : (stride == 2 ? (in_h + 1) / 2 : in_h);
   const int ow = upsample ? in_w * 2 : (stride == 2 ? (in_w + 1) / 2 : in_w);
@@ -853,6 +882,11 @@ int mvd_op_conv3x3(const void* x, int batch, int in_h, int in_w, int cin, int st
   g.W = (const bf16_t*)w; g.ldw = g.Ktot; g.M = batch * oh * ow; g.N = cout; g.rows_per_batch = oh * ow; g.outH = oh; g.outW = ow;
   g.bias = bias; g.rowvec = rowvec; g.ld_rowvec = ld_rowvec; g.res = (const bf16_t*)res; g.ldres = cout; g.alpha = 1.f;
   g.out = out; g.ldo = cout;
+  if (splitk > 1) {
+    g.splitk = splitk; g.part = splitk_ws;
+    if (int r = mvd_launch_gemm(g, (hipStream_t)stream, force_cfg)) return r;
+    return mvd_launch_splitk_reduce(g, (hipStream_t)stream);
+  }
   return mvd_launch_gemm(g, (hipStream_t)stream, force_cfg);
 }
 

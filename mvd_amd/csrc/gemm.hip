@@ -35,6 +35,10 @@ struct Cfg {
   static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
   static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
   static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+  // register budget: keep as many workgroups co-resident per CU as LDS allows (2nd __launch_bounds__ argument
+  // = waves per SIMD); without it hipcc spends up to 512 registers per lane and halves the residency
+  static constexpr int WG_PER_CU = (160 * 1024 / LDS_BYTES) > 4 ? 4 : (160 * 1024 / LDS_BYTES);
+  static constexpr int MIN_WAVES = (WG_PER_CU * NT / 256) < 1 ? 1 : (WG_PER_CU * NT / 256 > 4 ? 4 : WG_PER_CU * NT / 256);
   static_assert(WTM % 16 == 0 && WTN % 16 == 0, "wave tile must be a multiple of the MFMA tile");
   static_assert(A_CHUNKS % NT == 0, "A slab must divide evenly over the threads");
 };
@@ -53,19 +57,32 @@ MVD_DEVINL void glds16(const void* gsrc, void* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <class C, int AMODE, bool GLDS>
-__global__ __launch_bounds__(C::NT) void gemm_kernel(const MvdGemmArgs a) {
+// The kernel is PERSISTENT: gridDim.x workgroups walk the tile list (XCD-contiguous chunks) and the K-slab
+// pipeline runs straight across tile boundaries -- the first slab of the next tile is already in flight while
+// the last slab of the current tile is multiplied and its epilogue runs, so short-K GEMMs (K = 320: five slabs)
+// do not pay a load-latency prologue per tile.
+template <class C, int AMODE, bool GLDS, bool SPLITK>
+__global__ __launch_bounds__(C::NT, C::MIN_WAVES) void gemm_kernel(const MvdGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / C::WN, wn = wave % C::WN;
   const int ntn = a.N / C::BN;
   const int ntm = (a.M + C::BM - 1) / C::BM;
-  const int t = xcd_remap(blockIdx.x, ntn * ntm);
-  const int m0 = (t / ntn) * C::BM, n0 = (t % ntn) * C::BN;
   const int lrow = tid >> 3;
   // 16-byte K chunk this thread fetches: register staging swizzles the LDS address, LDS-DMA the source column
   const int kc = GLDS ? ((tid & 7) ^ ((lrow >> 1) & 7)) : (tid & 7);
   const int wave_chunk0 = tid & ~63;   // first chunk id of this wave (LDS-DMA destination is wave-uniform)
+
+  // ---- tile walk: XCD x (= blockIdx & 7) owns tiles [tstart, tstart + tcnt); its workgroups stride through them
+  const int S = SPLITK ? a.splitk : 1;            // split-K: each tile is S work items over disjoint slab ranges
+  const int ntiles = ntn * ntm * S;               // (work items)
+  const int xcd = blockIdx.x & 7, xj = blockIdx.x >> 3;
+  const int gx = (gridDim.x >> 3) + ((int)(gridDim.x & 7) > xcd ? 1 : 0);   // workgroups on this XCD
+  const int tq = ntiles >> 3, tr = ntiles & 7;
+  const int tstart = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+  const int tend = tstart + tq + (xcd < tr ? 1 : 0);
+  int tile = tstart + xj;
+  if (tile >= tend) return;
 
   constexpr bool HAS_CONV = AMODE != 0;
   const MvdASeg& cs = a.seg[0];                       // conv segment (AMODE 1, 2)
@@ -77,31 +94,42 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(const MvdGemmArgs a) {
   const bf16_t* dp1 = ds.p1;
   const int dc0 = ds.c0, dc1 = ds.c1;
   const int nkt_conv = HAS_CONV ? (9 * conv_c) / 64 : 0;
+  const int nkt = a.Ktot / 64;
 
-  // per-thread A row descriptors
+  // ---- loader state (belongs to the tile whose slabs are being fetched -- may run one tile ahead)
   int a_m[C::A_IT], a_pb[C::A_IT], a_iy[C::A_IT], a_ix[C::A_IT];
+  int ld_n0 = 0;
+  const int tpt = conv_c >> 6;            // slabs per conv tap
+  auto setup_loader = [&](int work) {
+    const int t = S == 1 ? work : work / S;
+    const int m0 = (t / ntn) * C::BM;
+    ld_n0 = (t % ntn) * C::BN;
 #pragma unroll
-  for (int i = 0; i < C::A_IT; ++i) {
-    int m = m0 + lrow + i * C::ROWS_PER_IT;
-    m = m < a.M ? m : a.M - 1;
-    a_m[i] = m;
-    a_pb[i] = 0; a_iy[i] = 0; a_ix[i] = 0;
-    if (HAS_CONV) {
-      const int b = m / a.rows_per_batch;
-      const int rem = m - b * a.rows_per_batch;
-      const int oy = rem / a.outW, ox = rem - oy * a.outW;
-      a_pb[i] = b * cs.inH * cs.inW;
-      a_iy[i] = oy * cs.stride - 1;
-      a_ix[i] = ox * cs.stride - 1;
+    for (int i = 0; i < C::A_IT; ++i) {
+      int m = m0 + lrow + i * C::ROWS_PER_IT;
+      m = m < a.M ? m : a.M - 1;
+      a_m[i] = m;
+      a_pb[i] = 0; a_iy[i] = 0; a_ix[i] = 0;
+      if (HAS_CONV) {
+        const int b = m / a.rows_per_batch;
+        const int rem = m - b * a.rows_per_batch;
+        const int oy = rem / a.outW, ox = rem - oy * a.outW;
+        a_pb[i] = b * cs.inH * cs.inW;
+        a_iy[i] = oy * cs.stride - 1;
+        a_ix[i] = ox * cs.stride - 1;
+      }
     }
-  }
+  };
 
   u32x4 ra[C::A_IT], rb[C::B_IT];
-  int ld_kt = 0, ld_tap = 0, ld_cc = 0;   // uniform cursor of the next slab to load
-
-  auto load_a = [&](int st) {
+  // fetch slab lk of the loader's tile into stage st (or into registers); the slab position (tap, channel
+  // offset) is derived from lk alone so that it stays in scalar registers
+  auto load_slab = [&](int st, int lk) {
     unsigned char* sa = smem + st * C::STAGE_BYTES;
-    if (HAS_CONV && (AMODE == 1 || ld_kt < nkt_conv)) {
+    unsigned char* sb = sa + C::A_BYTES;
+    if (HAS_CONV && (AMODE == 1 || lk < nkt_conv)) {
+      const int ld_tap = lk / tpt;
+      const int ld_cc = (lk - ld_tap * tpt) << 6;
       const int dy = ld_tap / 3, dx = ld_tap - dy * 3;
       const int col = ld_cc + kc * 8;
 #pragma unroll
@@ -118,9 +146,8 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(const MvdGemmArgs a) {
           ra[i] = v;
         }
       }
-      ld_cc += 64;
-      if (ld_cc >= conv_c) { ld_cc = 0; ++ld_tap; }
     } else {
+      const int ld_cc = (lk - nkt_conv) << 6;
       const bool first = ld_cc < dc0;
       const bf16_t* base = first ? dp0 : dp1;
       const int ld = first ? dc0 : dc1;
@@ -131,143 +158,257 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(const MvdGemmArgs a) {
         if (GLDS) glds16(p, sa + (wave_chunk0 + i * C::NT) * 16);
         else ra[i] = *reinterpret_cast<const u32x4*>(p);
       }
-      ld_cc += 64;
     }
-    ++ld_kt;
-  };
-  auto load_b = [&](int kt, int st) {
-    unsigned char* sb = smem + st * C::STAGE_BYTES + C::A_BYTES;
 #pragma unroll
     for (int i = 0; i < C::B_IT; ++i) {
       const int row = lrow + i * C::ROWS_PER_IT;
       if (C::B_CHUNKS % C::NT == 0 || row < C::BN) {
-        const bf16_t* p = a.W + (size_t)(n0 + row) * a.ldw + kt * 64 + kc * 8;
+        const bf16_t* p = a.W + (size_t)(ld_n0 + row) * a.ldw + lk * 64 + kc * 8;
         if (GLDS) glds16(p, sb + (wave_chunk0 + i * C::NT) * 16);
         else rb[i] = *reinterpret_cast<const u32x4*>(p);
       }
     }
   };
-  auto store_stage = [&](int st) {
+  auto commit_slab = [&](int st) {   // make the fetched slab visible in LDS stage st (before the barrier)
     if (GLDS) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
-    const int kc = tid & 7;
     unsigned char* sa = smem + st * C::STAGE_BYTES;
     unsigned char* sb = sa + C::A_BYTES;
+    const int kcr = tid & 7;
 #pragma unroll
     for (int i = 0; i < C::A_IT; ++i)
-      *reinterpret_cast<u32x4*>(sa + swz_off(lrow + i * C::ROWS_PER_IT, kc)) = ra[i];
+      *reinterpret_cast<u32x4*>(sa + swz_off(lrow + i * C::ROWS_PER_IT, kcr)) = ra[i];
 #pragma unroll
     for (int i = 0; i < C::B_IT; ++i) {
       const int row = lrow + i * C::ROWS_PER_IT;
-      if (C::B_CHUNKS % C::NT == 0 || row < C::BN) *reinterpret_cast<u32x4*>(sb + swz_off(row, kc)) = rb[i];
+      if (C::B_CHUNKS % C::NT == 0 || row < C::BN) *reinterpret_cast<u32x4*>(sb + swz_off(row, kcr)) = rb[i];
     }
   };
 
   f32x4 acc[C::TM][C::TN];
-#pragma unroll
-  for (int i = 0; i < C::TM; ++i)
-#pragma unroll
-    for (int j = 0; j < C::TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nkt = a.Ktot / 64;
-  load_a(0);
-  load_b(0, 0);
-  store_stage(0);
-  __syncthreads();
-
   const int fr = lane & 15, fq = lane >> 4;
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
-    const bool more = kt + 1 < nkt;
-    if (more) { load_a(cur ^ 1); load_b(kt + 1, cur ^ 1); }
-    const unsigned char* sa = smem + cur * C::STAGE_BYTES;
-    const unsigned char* sb = sa + C::A_BYTES;
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      bf16x8 af[C::TM], wf[C::TN];
-#pragma unroll
-      for (int i = 0; i < C::TM; ++i)
-        af[i] = *reinterpret_cast<const bf16x8*>(sa + swz_off(wm * C::WTM + i * 16 + fr, s2 * 4 + fq));
-#pragma unroll
-      for (int j = 0; j < C::TN; ++j)
-        wf[j] = *reinterpret_cast<const bf16x8*>(sb + swz_off(wn * C::WTN + j * 16 + fr, s2 * 4 + fq));
-#pragma unroll
-      for (int i = 0; i < C::TM; ++i)
-#pragma unroll
-        for (int j = 0; j < C::TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-    }
-    if (more) store_stage(cur ^ 1);
-    __syncthreads();
-  }
-
-  // ------------------------------------------------------------------ epilogue
-  // lane holds out[m][n..n+3]: m = tile row (lane&15), n = 4*(lane>>4) + reg
   const float alpha = a.alpha;
+
+  // The accumulators of a tile START at bias + per-batch row vector (out = alpha*(A.W^T + bias + rowvec) + res),
+  // so the epilogue needs no operand registers for them.  lane holds out[m][n..n+3]: m = tile row (lane&15),
+  // n = 4*(lane>>4) + reg.
+  auto init_acc = [&](int m0, int n0) {
+    const int nb = n0 + wn * C::WTN + fq * 4;
 #pragma unroll
-  for (int i = 0; i < C::TM; ++i) {
-    const int m = m0 + wm * C::WTM + i * 16 + fr;
-    if (m >= a.M) continue;
-    const float* rv = nullptr;
-    if (a.rowvec) rv = a.rowvec + (size_t)(m / a.rows_per_batch) * a.ld_rowvec;
-    if (!a.geglu) {
+    for (int i = 0; i < C::TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < C::TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (SPLITK) return;
+    if (a.bias) {
 #pragma unroll
       for (int j = 0; j < C::TN; ++j) {
-        const int n = n0 + wn * C::WTN + j * 16 + fq * 4;
-        f32x4 v = acc[i][j];
-        if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
-        if (rv) v += *reinterpret_cast<const f32x4*>(rv + n);
-        v *= alpha;
-        if (a.res) {
-          const u32x2 r = *reinterpret_cast<const u32x2*>(a.res + (size_t)m * a.ldres + n);
-          v[0] += bflo(r[0]); v[1] += bfhi(r[0]); v[2] += bflo(r[1]); v[3] += bfhi(r[1]);
-        }
-        if (a.out_f32) {
-          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + (size_t)m * a.ldo + n) = v;
-        } else {
-          u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-          *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.ldo + n) = o;
-        }
-      }
-    } else {
-      if constexpr (C::TN % 2 == 0) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + nb + j * 16);
 #pragma unroll
-        for (int j = 0; j < C::TN; j += 2) {
-          const int nv = n0 + wn * C::WTN + j * 16 + fq * 4;  // packed index of the value rows
-          f32x4 v = acc[i][j], g = acc[i][j + 1];
-          if (a.bias) {
-            v += *reinterpret_cast<const f32x4*>(a.bias + nv);
-            g += *reinterpret_cast<const f32x4*>(a.bias + nv + 16);
+        for (int i = 0; i < C::TM; ++i) acc[i][j] = bv;
+      }
+    }
+    if (a.rowvec) {
+#pragma unroll
+      for (int i = 0; i < C::TM; ++i) {
+        int m = m0 + wm * C::WTM + i * 16 + fr;
+        m = m < a.M ? m : a.M - 1;
+        const float* rv = a.rowvec + (size_t)(m / a.rows_per_batch) * a.ld_rowvec + nb;
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j) acc[i][j] += *reinterpret_cast<const f32x4*>(rv + j * 16);
+      }
+    }
+  };
+
+  // Residual loads are issued as one batch per row tile: while an LDS-DMA is in flight hipcc waits vmcnt(0) for
+  // every ordinary load, so load-use-load-use would serialise the epilogue into dozens of memory round trips.
+  auto epilogue = [&](int m0, int n0, int ks) {
+    const int nb = n0 + wn * C::WTN + fq * 4;
+    if (SPLITK) {   // raw fp32 partial tile; bias / residual / activation are applied by the reduce kernel
+      float* pp = a.part + (size_t)ks * a.M * a.N;
+#pragma unroll
+      for (int i = 0; i < C::TM; ++i) {
+        const int m = m0 + wm * C::WTM + i * 16 + fr;
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j)
+          if (m < a.M) *reinterpret_cast<f32x4*>(pp + (size_t)m * a.N + nb + j * 16) = acc[i][j];
+      }
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i) {
+      const int m = m0 + wm * C::WTM + i * 16 + fr;
+      const bool live = m < a.M;
+      const int mc = live ? m : a.M - 1;
+      if (!a.geglu) {
+        u32x2 res_r[C::TN];
+        if (a.res) {
+          const bf16_t* rp = a.res + (size_t)mc * a.ldres + nb;
+#pragma unroll
+          for (int j = 0; j < C::TN; ++j) res_r[j] = *reinterpret_cast<const u32x2*>(rp + j * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j) {
+          const int n = nb + j * 16;
+          f32x4 v = acc[i][j] * alpha;
+          if (a.res) {
+            v[0] += bflo(res_r[j][0]); v[1] += bfhi(res_r[j][0]); v[2] += bflo(res_r[j][1]); v[3] += bfhi(res_r[j][1]);
           }
-          const int no = (n0 + wn * C::WTN) / 2 + (j / 2) * 16 + fq * 4;
-          u32x2 o = {pack2bf(v[0] * gelu_erf_f(g[0]), v[1] * gelu_erf_f(g[1])),
-                     pack2bf(v[2] * gelu_erf_f(g[2]), v[3] * gelu_erf_f(g[3]))};
-          *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.ldo + no) = o;
+          if (!live || (a.dbg & 1)) continue;
+          if (a.out_f32) {
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + (size_t)m * a.ldo + n) = v;
+          } else {
+            u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+            *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.ldo + n) = o;
+          }
+        }
+      } else {
+        if constexpr (C::TN % 2 == 0) {
+#pragma unroll
+          for (int j = 0; j < C::TN; j += 2) {
+            const f32x4 v = acc[i][j], g = acc[i][j + 1];    // packed rows: 16 value | 16 gate (bias already in)
+            if (!live || (a.dbg & 1)) continue;
+            const int no = (n0 + wn * C::WTN) / 2 + (j / 2) * 16 + fq * 4;
+            u32x2 o = {pack2bf(v[0] * gelu_erf_f(g[0]), v[1] * gelu_erf_f(g[1])),
+                       pack2bf(v[2] * gelu_erf_f(g[2]), v[3] * gelu_erf_f(g[3]))};
+            *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.ldo + no) = o;
+          }
         }
       }
+    }
+  };
+
+  // slab range of a work item (all of K unless split-K); kept out of the slab loop: the integer divisions by
+  // the runtime split factor are ~40 instructions each
+  auto slab_range = [&](int work, int& k0, int& k1) {
+    if (S == 1) { k0 = 0; k1 = nkt; return; }
+    const int ks = work % S;
+    k0 = (ks * nkt) / S;
+    k1 = ((ks + 1) * nkt) / S;
+  };
+  int kt0, kt1;
+  slab_range(tile, kt0, kt1);
+  setup_loader(tile);
+  load_slab(0, kt0);
+  {
+    const int tl0 = S == 1 ? tile : tile / S;
+    init_acc((tl0 / ntn) * C::BM, (tl0 % ntn) * C::BN);
+  }
+  commit_slab(0);
+  __syncthreads();
+  int cur = 0;
+  for (;;) {
+    const int tl = S == 1 ? tile : tile / S;
+    const int ks = S == 1 ? 0 : tile - tl * S;
+    const int m0 = (tl / ntn) * C::BM, n0 = (tl % ntn) * C::BN;
+    const int next_tile = tile + gx;
+    const bool have_next = next_tile < tend;
+    int nkt0 = 0, nkt1 = 0;
+    if (have_next) slab_range(next_tile, nkt0, nkt1);
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const bool last_k = kt + 1 == kt1;
+      const bool more = !last_k || have_next;
+      if (more) {
+        if (last_k) setup_loader(next_tile);   // the loader runs ahead into the next work item
+        load_slab(cur ^ 1, last_k ? nkt0 : kt + 1);
+      }
+      const unsigned char* sa = smem + cur * C::STAGE_BYTES;
+      const unsigned char* sb = sa + C::A_BYTES;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 af[C::TM], wf[C::TN];
+#pragma unroll
+        for (int i = 0; i < C::TM; ++i)
+          af[i] = *reinterpret_cast<const bf16x8*>(sa + swz_off(wm * C::WTM + i * 16 + fr, s2 * 4 + fq));
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j)
+          wf[j] = *reinterpret_cast<const bf16x8*>(sb + swz_off(wn * C::WTN + j * 16 + fr, s2 * 4 + fq));
+        if (!(a.dbg & 2)) {
+#pragma unroll
+          for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+            for (int j = 0; j < C::TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int i = 0; i < C::TM; ++i) asm volatile("" :: "v"(af[i]));
+#pragma unroll
+          for (int j = 0; j < C::TN; ++j) asm volatile("" :: "v"(wf[j]));
+        }
+      }
+      if (last_k) {                            // next work item's first slab is in flight meanwhile
+        epilogue(m0, n0, ks);
+        if (have_next) {
+          const int tn = S == 1 ? next_tile : next_tile / S;
+          init_acc((tn / ntn) * C::BM, (tn % ntn) * C::BN);
+        }
+      }
+      if (more) commit_slab(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
+    if (!have_next) break;
+    tile = next_tile; kt0 = nkt0; kt1 = nkt1;
+  }
+}
+
+// ---------------------------------------------------------------- split-K reduction + epilogue
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const MvdGemmArgs a) {
+  const long nvec = (long)a.M * (a.N >> 2);
+  const int nv = a.N >> 2;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < nvec; e += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(e / nv), n = (int)(e - (long)m * nv) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(a.part + (size_t)m * a.N + n);
+    for (int s = 1; s < a.splitk; ++s) v += *reinterpret_cast<const f32x4*>(a.part + ((size_t)s * a.M + m) * a.N + n);
+    if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
+    if (a.rowvec) v += *reinterpret_cast<const f32x4*>(a.rowvec + (size_t)(m / a.rows_per_batch) * a.ld_rowvec + n);
+    v *= a.alpha;
+    if (a.res) {
+      const u32x2 r = *reinterpret_cast<const u32x2*>(a.res + (size_t)m * a.ldres + n);
+      v[0] += bflo(r[0]); v[1] += bfhi(r[0]); v[2] += bflo(r[1]); v[3] += bfhi(r[1]);
+    }
+    if (a.out_f32) {
+      *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + (size_t)m * a.ldo + n) = v;
+    } else {
+      u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+      *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.ldo + n) = o;
     }
   }
 }
 
 struct CfgInfo { int bm, bn, tn_even; };
 
-template <class C, int AMODE, bool GLDS>
-int launch_mode(const MvdGemmArgs& a, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<C, AMODE, GLDS>),
+template <class C, int AMODE, bool GLDS, bool SPLITK>
+int launch_mode2(const MvdGemmArgs& a, hipStream_t s) {
+  static int per_cu = 0;   // resident workgroups per CU for this instantiation (LDS- and VGPR-limited)
+  if (!per_cu) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<C, AMODE, GLDS, SPLITK>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     if (e != hipSuccess) { mvd_set_error("gemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return -2; }
-    attr_set = true;
+    int nb = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_kernel<C, AMODE, GLDS, SPLITK>, C::NT, C::LDS_BYTES);
+    if (e != hipSuccess || nb < 1) nb = 1;
+    per_cu = nb > 4 ? 4 : nb;
   }
   const int ntm = (a.M + C::BM - 1) / C::BM, ntn = a.N / C::BN;
-  hipLaunchKernelGGL((gemm_kernel<C, AMODE, GLDS>), dim3(ntm * ntn), dim3(C::NT), C::LDS_BYTES, s, a);
+  // persistent grid: as many workgroups as fit on the chip at once (LDS-limited), a multiple of the 8 XCDs
+  int grid = 256 * per_cu;
+  const int ntiles = ntm * ntn * (a.splitk > 1 ? a.splitk : 1);
+  if (ntiles < grid) grid = ((ntiles + 7) / 8) * 8;
+  hipLaunchKernelGGL((gemm_kernel<C, AMODE, GLDS, SPLITK>), dim3(grid), dim3(C::NT), C::LDS_BYTES, s, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { mvd_set_error("gemm launch: %s", hipGetErrorString(e)); return -3; }
   return 0;
 }
 
+template <class C, int AMODE, bool GLDS>
+int launch_mode(const MvdGemmArgs& a, hipStream_t s) {
+  if constexpr (GLDS) { if (a.splitk > 1) return launch_mode2<C, AMODE, true, true>(a, s); }
+  return launch_mode2<C, AMODE, GLDS, false>(a, s);
+}
+
 template <class C>
 int launch_cfg(const MvdGemmArgs& a, hipStream_t s, bool glds) {
+  if (a.splitk > 1) glds = true;   // split-K exists for the LDS-DMA variants only
   if (glds) {
     if (a.seg[0].mode == MVD_A_DENSE) return launch_mode<C, 0, true>(a, s);
     return a.nseg == 1 ? launch_mode<C, 1, true>(a, s) : launch_mode<C, 2, true>(a, s);
@@ -294,12 +435,17 @@ extern "C" int mvd_gemm_num_configs(void) { return kNumCfgs; }
 // until the grid has >= ~300 workgroups, else take the config with the most workgroups.
 int mvd_gemm_pick_config(const MvdGemmArgs& a) {
   static const int order[] = {2, 3, 4, 5};
-  int cfg = -1;
+  int cfg = -1, first_valid = -1;
   long best_blocks = -1;
   for (int c : order) {
     if (a.N % kCfgs[c].bn) continue;
     if (a.geglu && !kCfgs[c].tn_even) continue;
     const long blocks = (long)((a.M + kCfgs[c].bm - 1) / kCfgs[c].bm) * (a.N / kCfgs[c].bn);
+    if (first_valid < 0) {
+      first_valid = c;
+      // long K but too few tiles of the efficient shape: keep that tile, split-K supplies the parallelism
+      if (blocks < 300 && !a.geglu && a.Ktot / 64 >= 16 && c <= 3 && a.M >= 512) return c;
+    }
     if (blocks >= 300) return c;
     if (blocks > best_blocks) { best_blocks = blocks; cfg = c; }
   }
@@ -327,6 +473,7 @@ int mvd_launch_gemm(const MvdGemmArgs& a, hipStream_t s, int force_cfg) {
   if (a.ldw < a.Ktot || (a.ldw % 8) || !a.W) { mvd_set_error("gemm: bad weight stride ldw=%d (K=%d)", a.ldw, a.Ktot); return -1; }
   if (a.rows_per_batch <= 0) { mvd_set_error("gemm: rows_per_batch must be > 0"); return -1; }
   if (a.N % 64) { mvd_set_error("gemm: N=%d must be a multiple of 64", a.N); return -1; }
+  if (a.splitk > 1 && (!a.part || a.geglu || a.splitk > 16 || a.splitk > a.Ktot / 64)) { mvd_set_error("gemm: bad split-K request (splitk=%d)", a.splitk); return -1; }
   if (a.geglu && (a.out_f32 || a.res || a.rowvec)) { mvd_set_error("gemm: unsupported GEGLU epilogue combination"); return -1; }
   const int on = a.geglu ? a.N / 2 : a.N;
   if (a.ldo < on || (a.ldo % 4) || (a.res && (a.ldres % 4))) { mvd_set_error("gemm: bad leading dims"); return -1; }
@@ -334,6 +481,8 @@ int mvd_launch_gemm(const MvdGemmArgs& a, hipStream_t s, int force_cfg) {
   // force_cfg: -1 = heuristic; 0..5 = tile config with register staging; 8..13 = same tiles with LDS-DMA staging
   static const int default_glds = [] { const char* e = getenv("MVD_GEMM_GLDS"); return e ? atoi(e) : 1; }();
   bool glds = default_glds != 0;
+  static const int dbg = [] { const char* e = getenv("MVD_GEMM_DEBUG"); return e ? atoi(e) : 0; }();
+  if (dbg) const_cast<MvdGemmArgs&>(a).dbg = dbg;
   int cfg = force_cfg;
   if (cfg >= 8) { glds = true; cfg -= 8; } else if (cfg >= 0) { glds = false; }
   if (cfg < 0) cfg = mvd_gemm_pick_config(a);
@@ -346,4 +495,30 @@ int mvd_launch_gemm(const MvdGemmArgs& a, hipStream_t s, int force_cfg) {
     case 4: return launch_cfg<C4>(a, s, glds);
     default: return launch_cfg<C5>(a, s, glds);
   }
+}
+
+// Split-K heuristic: GEMMs whose tile grid cannot fill the chip (deep levels: M = batch * 64 pixels) but whose K
+// is long are cut along K so that ~512 work items exist; the partials are summed by splitk_reduce_kernel.
+int mvd_gemm_pick_splitk(const MvdGemmArgs& a) {
+  if (a.geglu) return 1;
+  const int cfg = mvd_gemm_pick_config(a);
+  if (cfg < 0) return 1;
+  const long tiles = (long)((a.M + kCfgs[cfg].bm - 1) / kCfgs[cfg].bm) * (a.N / kCfgs[cfg].bn);
+  const int nkt = a.Ktot / 64;
+  if (tiles >= 256 || nkt < 16) return 1;
+  long s = 512 / tiles;
+  if (s > nkt / 8) s = nkt / 8;
+  if (s > 8) s = 8;
+  return s < 2 ? 1 : (int)s;
+}
+
+int mvd_launch_splitk_reduce(const MvdGemmArgs& a, hipStream_t s) {
+  if (a.splitk < 2 || !a.part || (a.N & 3)) { mvd_set_error("splitk_reduce: bad arguments"); return -1; }
+  const long nvec = (long)a.M * (a.N >> 2);
+  int grid = (int)((nvec + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, s, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { mvd_set_error("splitk_reduce launch: %s", hipGetErrorString(e)); return -3; }
+  return 0;
 }

@@ -39,9 +39,16 @@ struct MvdGemmArgs {
   void* out;
   int ldo;
   int out_f32;            // 1: fp32 output, else bf16
+  int splitk;             // > 1: K is split over `splitk` work items per tile; raw fp32 partial tiles go to `part`
+  float* part;            // [splitk][M][N] fp32 partials (then mvd_launch_splitk_reduce applies the epilogue)
+  int dbg;                // measurement only (env MVD_GEMM_DEBUG): bit0 skip the output stores, bit1 skip the MFMAs
 };
 
 int mvd_launch_gemm(const MvdGemmArgs& a, hipStream_t s, int force_cfg = -1);
+// sum the split-K partials and apply the GEMM epilogue (bias, row vector, alpha, residual) -> out
+int mvd_launch_splitk_reduce(const MvdGemmArgs& a, hipStream_t s);
+// split factor the engine should use for this problem (1 = none); needs splitk*M*N floats of workspace
+int mvd_gemm_pick_splitk(const MvdGemmArgs& a);
 
 // ---------------------------------------------------------------- attention (head_dim 64)
 struct MvdAttnProblem {

@@ -7,7 +7,7 @@ One-time host work (torch is used as plumbing for the permutes / casts).  Slot l
   resnet conv2  conv2 | conv_shortcut(1x1) concatenated along K, biases summed
   attn1.qkv     [to_q; to_k; to_v; (to_q_ref)]            rows concatenated
   attn1.out     [to_out.0 | ref_scale * to_out_ref.0]     K concatenated, bias = b + ref_scale*b_ref
-  attn2.q       [to_q; (to_q_ref)]     attn2.kv [to_k; to_v]
+  attn2.q       [to_q; (to_q_ref)]     text_kv: every attn2 site's [to_k; to_v] stacked in module order
   ref_kv        [to_k_ref(self); to_v_ref(self); to_k_ref(cross); to_v_ref(cross)]
   ff1           GEGLU rows interleaved in blocks of 16: (16 value rows, 16 gate rows)
   temb_proj     every resnet's time_emb_proj stacked in module order (one GEMM per forward)
@@ -74,6 +74,7 @@ def pack_unet(sd: Dict[str, torch.Tensor], cfg: UNetConfig, device, adapter: boo
     out["temb_proj.w"] = _bf(torch.cat(tw, 0), device)
     out["temb_proj.b"] = _f32(torch.cat(tb, 0), device)
 
+    tkv = []   # text K/V projections of every attn2 site, stacked in module order (one GEMM per pass)
     for key, _feat, C, _heads in cfg.transformers():
         b = f"{key}.transformer_blocks.0"
         out[f"{key}.norm.g"] = _f32(sd[f"{key}.norm.weight"], device)
@@ -105,12 +106,13 @@ def pack_unet(sd: Dict[str, torch.Tensor], cfg: UNetConfig, device, adapter: boo
                                                     f(f"{p2}.to_k_ref.weight"), f(f"{p2}.to_v_ref.weight")], 0), device)
         out[f"{key}.attn1.qkv.w"] = _bf(torch.cat(qkv, 0), device)
         out[f"{key}.attn2.q.w"] = _bf(torch.cat(q2, 0), device)
-        out[f"{key}.attn2.kv.w"] = _bf(torch.cat([f(f"{b}.attn2.to_k.weight"), f(f"{b}.attn2.to_v.weight")], 0), device)
+        tkv.append(torch.cat([f(f"{b}.attn2.to_k.weight"), f(f"{b}.attn2.to_v.weight")], 0))
         out[f"{key}.ff1.w"] = _bf(_geglu_rows(f(f"{b}.ff.net.0.proj.weight")), device)
         out[f"{key}.ff1.b"] = _f32(_geglu_rows(f(f"{b}.ff.net.0.proj.bias")), device)
         out[f"{key}.ff2.w"] = _bf(sd[f"{b}.ff.net.2.weight"], device)
         out[f"{key}.ff2.b"] = _f32(sd[f"{b}.ff.net.2.bias"], device)
 
+    out["text_kv.w"] = _bf(torch.cat(tkv, 0), device)
     n = cfg.num_levels
     for i in range(n - 1):
         out[f"down_blocks.{i}.down.w"] = _bf(_conv_w(sd[f"down_blocks.{i}.downsamplers.0.conv.weight"]), device)

@@ -99,7 +99,10 @@ def test_packing_layouts(tiny_model):
     torch.testing.assert_close(wo[:, C:].float(), (0.3 * sd[f"{b}.attn2.processor.to_out_ref.0.weight"]).to(torch.bfloat16).float())
     torch.testing.assert_close(packed[f"{k}.attn2.out.b"], sd[f"{b}.attn2.to_out.0.bias"] + 0.3 * sd[f"{b}.attn2.processor.to_out_ref.0.bias"])
     torch.testing.assert_close(packed[f"{k}.attn2.out.b0"], sd[f"{b}.attn2.to_out.0.bias"])
-    assert packed[f"{k}.ref_kv.w"].shape == (4 * C, C) and packed[f"{k}.attn2.kv.w"].shape == (2 * C, 128)
+    assert packed[f"{k}.ref_kv.w"].shape == (4 * C, C)
+    ntkv = sum(2 * c for _, _, c, _ in UNetConfig.tiny().transformers())
+    assert packed["text_kv.w"].shape == (ntkv, 128)
+    torch.testing.assert_close(packed["text_kv.w"][C:2 * C].float(), sd[f"{b}.attn2.to_v.weight"].to(torch.bfloat16).float())
     # conv: [Cout][ky][kx][Cin]; resnet conv2 carries the 1x1 shortcut along K; conv_in padded to one K slab
     r = "down_blocks.1.resnets.0"
     w2 = packed[f"{r}.conv2.w"]

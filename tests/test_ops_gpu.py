@@ -35,6 +35,11 @@ def close(got, want, tol=2 ** -7, what=""):
     return rel_l2
 
 
+def _pack(w):
+    co, ci = w.shape[:2]
+    return w.float().permute(0, 2, 3, 1).reshape(co, -1).to(torch.bfloat16)
+
+
 # ------------------------------------------------------------------------------- GEMM
 # tile configs 0..5 use register staging, 8..13 the same tiles with LDS-DMA (global_load_lds) staging
 @pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4, 5, 8, 9, 10, 11, 12, 13])
@@ -48,6 +53,25 @@ def test_linear_configs(ops, cfg, m, n, k):
     want = a.float() @ w.float().T + bias
     got = ops.linear(a.cuda(), w.cuda(), bias.cuda(), force_cfg=cfg)
     close(got, want, what=f"linear cfg{cfg}")
+
+
+@pytest.mark.parametrize("splitk", [2, 3, 5])
+@pytest.mark.parametrize("cfg", [-1, 10, 13])
+def test_linear_and_conv_splitk(ops, splitk, cfg):
+    """Split-K: K slabs divided over several work items per tile, fp32 partials, fused reduce + epilogue."""
+    m, n, k, rpb = 100, 320, 640, 50
+    a, w = rnd(m, k, seed=1), rnd(n, k, scale=1 / math.sqrt(k), seed=2)
+    bias, rowvec, res = rnd(n, seed=3, dtype=torch.float32), rnd(m // rpb, n, seed=4, dtype=torch.float32), rnd(m, n, seed=5)
+    want = (a.float() @ w.float().T + bias + rowvec.repeat_interleave(rpb, 0)) + res.float()
+    got = ops.linear(a.cuda(), w.cuda(), bias.cuda(), rowvec=rowvec.cuda(), rows_per_batch=rpb, res=res.cuda(),
+                     force_cfg=cfg, splitk=splitk)
+    close(got, want, what=f"linear splitk={splitk}")
+    B, H, W, cin, cout = 2, 6, 6, 128, 320
+    x = rnd(B, cin, H, W, seed=6)
+    wc = rnd(cout, cin, 3, 3, scale=1 / math.sqrt(9 * cin), seed=7)
+    want = F.conv2d(x.float(), wc.float(), bias, padding=1).permute(0, 2, 3, 1)
+    got = ops.conv3x3(x.permute(0, 2, 3, 1).contiguous().cuda(), _pack(wc).cuda(), bias.cuda(), force_cfg=cfg, splitk=splitk)
+    close(got, want, what=f"conv splitk={splitk}")
 
 
 def test_linear_epilogues(ops):
@@ -81,10 +105,6 @@ def test_linear_geglu(ops, cfg):
 
 
 # ------------------------------------------------------------------------------- conv
-def _pack(w):
-    co, ci = w.shape[:2]
-    return w.float().permute(0, 2, 3, 1).reshape(co, -1).to(torch.bfloat16)
-
 
 @pytest.mark.parametrize("cfg", [-1, 5, 13])
 @pytest.mark.parametrize("stride,ups", [(1, False), (2, False), (1, True)])
