@@ -97,9 +97,8 @@ __global__ __launch_bounds__(C::NT, C::MIN_WAVES) void gemm_kernel(const MvdGemm
   const int nkt = a.Ktot / 64;
 
   // ---- loader state (belongs to the tile whose slabs are being fetched -- may run one tile ahead)
-  int a_m[C::A_IT], a_pb[C::A_IT], a_iy[C::A_IT], a_ix[C::A_IT];
+  int a_m[C::A_IT], a_pb[C::A_IT], a_yx[C::A_IT];   // a_yx = (oy*stride) | (ox*stride) << 16
   int ld_n0 = 0;
-  const int tpt = conv_c >> 6;            // slabs per conv tap
   auto setup_loader = [&](int work) {
     const int t = S == 1 ? work : work / S;
     const int m0 = (t / ntn) * C::BM;
@@ -109,14 +108,13 @@ __global__ __launch_bounds__(C::NT, C::MIN_WAVES) void gemm_kernel(const MvdGemm
       int m = m0 + lrow + i * C::ROWS_PER_IT;
       m = m < a.M ? m : a.M - 1;
       a_m[i] = m;
-      a_pb[i] = 0; a_iy[i] = 0; a_ix[i] = 0;
+      a_pb[i] = 0; a_yx[i] = 0;
       if (HAS_CONV) {
         const int b = m / a.rows_per_batch;
         const int rem = m - b * a.rows_per_batch;
         const int oy = rem / a.outW, ox = rem - oy * a.outW;
         a_pb[i] = b * cs.inH * cs.inW;
-        a_iy[i] = oy * cs.stride - 1;
-        a_ix[i] = ox * cs.stride - 1;
+        a_yx[i] = (oy * cs.stride) | ((ox * cs.stride) << 16);
       }
     }
   };
@@ -128,13 +126,17 @@ __global__ __launch_bounds__(C::NT, C::MIN_WAVES) void gemm_kernel(const MvdGemm
     unsigned char* sa = smem + st * C::STAGE_BYTES;
     unsigned char* sb = sa + C::A_BYTES;
     if (HAS_CONV && (AMODE == 1 || lk < nkt_conv)) {
-      const int ld_tap = lk / tpt;
-      const int ld_cc = (lk - ld_tap * tpt) << 6;
+      // conv K order is [channel slice][tap][64 channels]: the nine taps of one 64-channel slice are consecutive
+      // slabs, so a workgroup re-reads the same ~50 KB of the feature map nine times from L2 instead of cycling
+      // through the whole 3-row x C window (~250 KB per workgroup, > L2 per XCD with 64 resident workgroups)
+      const int ld_cs = lk / 9;
+      const int ld_tap = lk - ld_cs * 9;
+      const int ld_cc = ld_cs << 6;
       const int dy = ld_tap / 3, dx = ld_tap - dy * 3;
       const int col = ld_cc + kc * 8;
 #pragma unroll
       for (int i = 0; i < C::A_IT; ++i) {
-        const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
+        const int iy = (a_yx[i] & 0xffff) - 1 + dy, ix = (a_yx[i] >> 16) - 1 + dx;
         const bool ok = (unsigned)iy < (unsigned)limH && (unsigned)ix < (unsigned)limW;
         const int sy = conv_ups ? (iy >> 1) : iy, sx = conv_ups ? (ix >> 1) : ix;
         const bf16_t* p = conv_p + (size_t)(a_pb[i] + sy * conv_inW + sx) * conv_c + col;
@@ -192,6 +194,7 @@ __global__ __launch_bounds__(C::NT, C::MIN_WAVES) void gemm_kernel(const MvdGemm
   // so the epilogue needs no operand registers for them.  lane holds out[m][n..n+3]: m = tile row (lane&15),
   // n = 4*(lane>>4) + reg.
   auto init_acc = [&](int m0, int n0) {
+    asm volatile("" : "+s"(m0), "+s"(n0));   // keep the address arithmetic here (not hoisted into live registers)
     const int nb = n0 + wn * C::WTN + fq * 4;
 #pragma unroll
     for (int i = 0; i < C::TM; ++i) {
@@ -222,6 +225,7 @@ __global__ __launch_bounds__(C::NT, C::MIN_WAVES) void gemm_kernel(const MvdGemm
   // Residual loads are issued as one batch per row tile: while an LDS-DMA is in flight hipcc waits vmcnt(0) for
   // every ordinary load, so load-use-load-use would serialise the epilogue into dozens of memory round trips.
   auto epilogue = [&](int m0, int n0, int ks) {
+    asm volatile("" : "+s"(m0), "+s"(n0));   // keep the address arithmetic here (not hoisted into live registers)
     const int nb = n0 + wn * C::WTN + fq * 4;
     if (SPLITK) {   // raw fp32 partial tile; bias / residual / activation are applied by the reduce kernel
       float* pp = a.part + (size_t)ks * a.M * a.N;
@@ -315,6 +319,25 @@ __global__ __launch_bounds__(C::NT, C::MIN_WAVES) void gemm_kernel(const MvdGemm
       const unsigned char* sb = sa + C::A_BYTES;
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
+        if constexpr (C::TM > 4) {
+          // tall wave tile (128 rows): 160 accumulator registers, so the A fragments are streamed two at a time
+          // (sched_barrier keeps hipcc from hoisting all eight reads and spilling)
+          bf16x8 wf[C::TN];
+#pragma unroll
+          for (int j = 0; j < C::TN; ++j)
+            wf[j] = *reinterpret_cast<const bf16x8*>(sb + swz_off(wn * C::WTN + j * 16 + fr, s2 * 4 + fq));
+#pragma unroll
+          for (int i = 0; i < C::TM; i += 2) {
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(sa + swz_off(wm * C::WTM + i * 16 + fr, s2 * 4 + fq));
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(sa + swz_off(wm * C::WTM + (i + 1) * 16 + fr, s2 * 4 + fq));
+#pragma unroll
+            for (int j = 0; j < C::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], a0, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < C::TN; ++j) acc[i + 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], a1, acc[i + 1][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          continue;
+        }
         bf16x8 af[C::TM], wf[C::TN];
 #pragma unroll
         for (int i = 0; i < C::TM; ++i)
@@ -423,8 +446,10 @@ using C2 = Cfg<128, 160, 2, 2>;
 using C3 = Cfg<128, 128, 2, 2>;
 using C4 = Cfg<128, 64, 2, 2>;
 using C5 = Cfg<64, 64, 2, 2>;
-const CfgInfo kCfgs[] = {{256, 160, 0}, {256, 128, 1}, {128, 160, 0}, {128, 128, 1}, {128, 64, 1}, {64, 64, 1}};
-constexpr int kNumCfgs = 6;
+using C7 = Cfg<256, 320, 2, 4>;   // wave tile 128x80: 49 FLOP per LDS-read byte instead of 36
+// (config 6 was a three-stage 256x160 experiment: no gain, the kernel is LDS-read bound, not load-latency bound)
+const CfgInfo kCfgs[] = {{256, 160, 0}, {256, 128, 1}, {128, 160, 0}, {128, 128, 1}, {128, 64, 1}, {64, 64, 1}, {0, 1 << 30, 0}, {256, 320, 0}};
+constexpr int kNumCfgs = 8;
 
 }  // namespace
 
@@ -434,6 +459,13 @@ extern "C" int mvd_gemm_num_configs(void) { return kNumCfgs; }
 // co-resident workgroups per CU) beats the 256-row tiles on every shape of the forward; fall to smaller tiles
 // until the grid has >= ~300 workgroups, else take the config with the most workgroups.
 int mvd_gemm_pick_config(const MvdGemmArgs& a) {
+  // 256x320 tile with 128x80 wave tiles (49 FLOP per LDS-read byte): the kernel is LDS-bandwidth bound, so this
+  // is the fastest shape whenever its tile grid -- times a split-K of up to 8 -- can occupy the 256 CUs
+  static const int use7 = [] { const char* e = getenv("MVD_GEMM_BIG"); return e ? atoi(e) : 1; }();
+  if (use7 && !a.geglu && a.N % 320 == 0 && a.M >= 1024) {
+    const long t7 = (long)((a.M + 255) / 256) * (a.N / 320);
+    if (t7 >= 200 || (a.Ktot / 64 >= 16 && t7 * 8 >= 200)) return 7;
+  }
   static const int order[] = {2, 3, 4, 5};
   int cfg = -1, first_valid = -1;
   long best_blocks = -1;
@@ -484,7 +516,7 @@ int mvd_launch_gemm(const MvdGemmArgs& a, hipStream_t s, int force_cfg) {
   static const int dbg = [] { const char* e = getenv("MVD_GEMM_DEBUG"); return e ? atoi(e) : 0; }();
   if (dbg) const_cast<MvdGemmArgs&>(a).dbg = dbg;
   int cfg = force_cfg;
-  if (cfg >= 8) { glds = true; cfg -= 8; } else if (cfg >= 0) { glds = false; }
+  if (cfg >= 8) { glds = true; cfg -= 8; } else if (cfg >= 0 && cfg < 6) { glds = false; }
   if (cfg < 0) cfg = mvd_gemm_pick_config(a);
   if (cfg < 0 || cfg >= kNumCfgs || a.N % kCfgs[cfg].bn || (a.geglu && !kCfgs[cfg].tn_even)) { mvd_set_error("gemm: no tile config for N=%d geglu=%d cfg=%d", a.N, a.geglu, cfg); return -1; }
   switch (cfg) {
@@ -493,6 +525,7 @@ int mvd_launch_gemm(const MvdGemmArgs& a, hipStream_t s, int force_cfg) {
     case 2: return launch_cfg<C2>(a, s, glds);
     case 3: return launch_cfg<C3>(a, s, glds);
     case 4: return launch_cfg<C4>(a, s, glds);
+    case 7: return launch_cfg<C7>(a, s, true);
     default: return launch_cfg<C5>(a, s, glds);
   }
 }
@@ -505,6 +538,13 @@ int mvd_gemm_pick_splitk(const MvdGemmArgs& a) {
   if (cfg < 0) return 1;
   const long tiles = (long)((a.M + kCfgs[cfg].bm - 1) / kCfgs[cfg].bm) * (a.N / kCfgs[cfg].bn);
   const int nkt = a.Ktot / 64;
+  if (cfg == 7) {   // one 147 KB workgroup per CU: aim for 256 work items
+    if (tiles >= 200 || nkt < 16) return 1;
+    long s7 = (256 + tiles - 1) / tiles;
+    if (s7 > nkt / 8) s7 = nkt / 8;
+    if (s7 > 8) s7 = 8;
+    return s7 < 2 ? 1 : (int)s7;
+  }
   if (tiles >= 256 || nkt < 16) return 1;
   long s = 512 / tiles;
   if (s > nkt / 8) s = nkt / 8;

@@ -3,7 +3,7 @@
 One-time host work (torch is used as plumbing for the permutes / casts).  Slot layouts
 (documented in DESIGN.md "Weight slots"):
 
-  conv          [Cout][ky][kx][Cin] bf16  (K = 9*Cin contiguous, tap-major)
+  conv          [Cout][Cin/64][ky][kx][64] bf16  (K = 9*Cin; channel-slice major, taps inner)
   resnet conv2  conv2 | conv_shortcut(1x1) concatenated along K, biases summed
   attn1.qkv     [to_q; to_k; to_v; (to_q_ref)]            rows concatenated
   attn1.out     [to_out.0 | ref_scale * to_out_ref.0]     K concatenated, bias = b + ref_scale*b_ref
@@ -29,9 +29,15 @@ def _f32(t: torch.Tensor, device) -> torch.Tensor:
     return t.detach().to(device=device, dtype=torch.float32).contiguous()
 
 
-def _conv_w(w: torch.Tensor) -> torch.Tensor:
+def _conv_w(w: torch.Tensor, tap_major: bool = False) -> torch.Tensor:
+    """[Cout][Cin][3][3] -> [Cout][K].  Implicit-GEMM convs use K = [Cin/64][ky][kx][64] (channel-slice major: the
+    nine taps of a 64-channel slice are consecutive K slabs -> L2-resident re-reads); conv_in / conv_out (and any
+    Cin that is not a multiple of 64) use the plain tap-major [ky][kx][Cin]."""
     co, ci, kh, kw = w.shape
-    return w.detach().float().permute(0, 2, 3, 1).reshape(co, kh * kw * ci)
+    w = w.detach().float()
+    if tap_major or ci % 64:
+        return w.permute(0, 2, 3, 1).reshape(co, kh * kw * ci)
+    return w.reshape(co, ci // 64, 64, kh, kw).permute(0, 1, 3, 4, 2).reshape(co, kh * kw * ci)
 
 
 def _geglu_rows(w: torch.Tensor) -> torch.Tensor:
@@ -47,7 +53,7 @@ def _geglu_rows(w: torch.Tensor) -> torch.Tensor:
 def pack_unet(sd: Dict[str, torch.Tensor], cfg: UNetConfig, device, adapter: bool, ref_scale: float = 0.0) -> Dict[str, torch.Tensor]:
     """``sd`` holds diffusers keys (no wrapper prefix) and, when ``adapter``, the ``...processor.*`` keys."""
     out: Dict[str, torch.Tensor] = {}
-    w_in = _conv_w(sd["conv_in.weight"])                       # [C0][9*Cin] -> zero padded to K = 64 (one MFMA slab)
+    w_in = _conv_w(sd["conv_in.weight"], tap_major=True)                       # [C0][9*Cin] -> zero padded to K = 64 (one MFMA slab)
     out["conv_in.w"] = _bf(torch.nn.functional.pad(w_in, (0, 64 - w_in.shape[1])), device)
     out["conv_in.b"] = _f32(sd["conv_in.bias"], device)
     out["time.l1.w"] = _bf(sd["time_embedding.linear_1.weight"], device)
@@ -121,7 +127,7 @@ def pack_unet(sd: Dict[str, torch.Tensor], cfg: UNetConfig, device, adapter: boo
         out[f"up_blocks.{i}.up.b"] = _f32(sd[f"up_blocks.{i}.upsamplers.0.conv.bias"], device)
     out["conv_norm_out.g"] = _f32(sd["conv_norm_out.weight"], device)
     out["conv_norm_out.b"] = _f32(sd["conv_norm_out.bias"], device)
-    out["conv_out.w"] = _bf(_conv_w(sd["conv_out.weight"]), device)
+    out["conv_out.w"] = _bf(_conv_w(sd["conv_out.weight"], tap_major=True), device)
     out["conv_out.b"] = _f32(sd["conv_out.bias"], device)
     return out
 

@@ -108,7 +108,8 @@ def test_packing_layouts(tiny_model):
     w2 = packed[f"{r}.conv2.w"]
     assert w2.shape == (128, 9 * 128 + 64)
     torch.testing.assert_close(w2[:, 9 * 128:].float(), sd[f"{r}.conv_shortcut.weight"].reshape(128, 64).to(torch.bfloat16).float())
-    torch.testing.assert_close(w2[5, 128 * 4:128 * 5].float(), sd[f"{r}.conv2.weight"][5, :, 1, 1].to(torch.bfloat16).float())
+    # K order [Cin/64][ky][kx][64]: slice 1 (channels 64..127), centre tap (index 4)
+    torch.testing.assert_close(w2[5, 9 * 64 + 4 * 64:9 * 64 + 5 * 64].float(), sd[f"{r}.conv2.weight"][5, 64:128, 1, 1].to(torch.bfloat16).float())
     assert packed["conv_in.w"].shape == (64, 64) and (packed["conv_in.w"][:, 36:] == 0).all()
     total = sum(co for _, _, co in UNetConfig.tiny().resnets())
     assert packed["temb_proj.w"].shape == (total, 256) and total % 64 == 0

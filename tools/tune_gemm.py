@@ -8,6 +8,7 @@ from mvd_amd import ops
 B = int(os.environ.get("TUNE_B", "32"))
 TILES = {0: (256, 160), 1: (256, 128), 2: (128, 160), 3: (128, 128), 4: (128, 64), 5: (64, 64)}
 TILES.update({k + 8: v for k, v in list(TILES.items())})
+TILES[7] = (256, 320)
 
 def time_fn(fn, iters=5):
     fn(); torch.cuda.synchronize()
