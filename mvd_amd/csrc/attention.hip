@@ -18,6 +18,7 @@
 //   online softmax in exp2 domain with the softmax scale folded into one v_fma.
 // K/V tiles (64 keys) are double buffered in LDS; global loads for tile t+1 are issued
 // before the MFMAs of tile t and written after them.
+#include <stdlib.h>
 #include "kernels.h"
 
 namespace {
@@ -25,6 +26,7 @@ namespace {
 constexpr int KV_TILE = 64;
 constexpr int TILE_BYTES = KV_TILE * 128;  // 64 keys x 64 dims x 2 B
 constexpr float NEG_BIG = -1.0e30f;
+constexpr float RESCALE_LOG2 = 6.0f;   // defer the online-softmax rescale while P stays below 2^6
 
 MVD_DEVINL int k_off(int key, int chunk) { return key * 128 + ((chunk ^ ((key >> 1) & 7)) << 4); }
 // V swizzle keeps 64-byte halves intact for the 4x16 transposed reads
@@ -44,8 +46,9 @@ MVD_DEVINL float pair_other(float x, float& own) {
 MVD_DEVINL float pair_max(float x) { float o; const float p = pair_other(x, o); return fmaxf(o, p); }
 MVD_DEVINL float pair_sum(float x) { float o; const float p = pair_other(x, o); return o + p; }
 
+// 2nd launch-bound = waves per SIMD: three 4-wave workgroups (12 waves) stay co-resident per CU
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void attn_kernel(const MvdAttnArgs a) {
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void attn_kernel(const MvdAttnArgs a) {
   constexpr int NT = 64 * NW;
   constexpr int QB = 32 * NW;
   constexpr int LD_IT = (KV_TILE * 8) / NT;  // 16-byte chunks per thread per tile
@@ -104,7 +107,11 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(const MvdAttnArgs a) {
   };
 
   f32x16 o0 = {}, o1 = {};       // O^T tiles: d 0..31 and 32..63 (rows) x query (lane)
-  float m_run = NEG_BIG, l_run = 0.f;
+  f32x16 ol = {};                // "ones" tile: row 0 (reg 0 of lanes 0..31) = running softmax denominators
+  bf16x8 ones_frag;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones_frag[j] = (lq == 0) ? (__bf16)1.0f : (__bf16)0.0f;
+  float m_run = NEG_BIG;
   const float c = a.scale * 1.4426950408889634f;  // scale * log2(e)
 
   const int nkb = (nk + KV_TILE - 1) / KV_TILE;
@@ -116,6 +123,13 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(const MvdAttnArgs a) {
   const int tr_i = lane & 15;
   const int tr_q = tr_i >> 2, tr_p = tr_i & 3;
   const int tr_dcol = ((lane >> 4) & 1) * 16 + tr_p * 4;   // dim offset inside a 32-dim tile
+  // Loop-invariant LDS byte offsets.  The V swizzle bit depends on (key>>1)&1 only, which is unchanged by
+  // +16*st and +8, so the two d tiles differ by an XOR of 64 bytes and everything else is an immediate.
+  const int tr_base0 = v_off(4 * lh + tr_q, tr_dcol >> 3) + (tr_dcol & 7) * 2;
+  const int tr_base1 = tr_base0 ^ 64;
+  int k_base[4];   // K row lq, chunk (2*ks + lh) ^ swizzle(lq); rows lq+32 share the swizzle
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) k_base[ks] = k_off(lq, ks * 2 + lh);
 
   for (int kb = 0; kb < nkb; ++kb) {
     const int cur = kb & 1;
@@ -128,8 +142,8 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(const MvdAttnArgs a) {
     f32x16 s0 = {}, s1 = {};
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(sk + k_off(lq, ks * 2 + lh));
-      const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(sk + k_off(32 + lq, ks * 2 + lh));
+      const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(sk + k_base[ks]);
+      const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(sk + k_base[ks] + 32 * 128);
       s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[ks], s0, 0, 0, 0);
       s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[ks], s1, 0, 0, 0);
     }
@@ -149,20 +163,23 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(const MvdAttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s1[r]);
     mx = pair_max(mx);
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-    const float mc = m_new * c;
-    m_run = m_new;
-    float psum = 0.f;
+    // Deferred rescale: the running max is only raised (and O / the row sums rescaled) when some row's max
+    // grew by more than RESCALE_LOG2 in the exp2 domain; otherwise P is taken against the old max and is bounded
+    // by 2^RESCALE_LOG2 (bf16 keeps its relative precision, the accumulators are fp32).  Wave-uniform branch.
+    if (!__all((mx - m_run) * c <= RESCALE_LOG2)) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+      m_run = m_new;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+      ol[0] *= alpha;                       // row sums live in row 0 of the "ones" tile
+    }
+    const float mc = m_run * c;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], c, -mc));   // raw v_exp_f32: arguments are <= 0
+      s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], c, -mc));   // raw v_exp_f32
       s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], c, -mc));
-      psum += s0[r] + s1[r];
     }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
 
     // ---- P^T as bf16 B operands: k-step s (16 keys) of sub tile t = accumulator regs 8s..8s+7
     bf16x8 pb[4];
@@ -178,10 +195,8 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(const MvdAttnArgs a) {
     for (int st = 0; st < 4; ++st) {          // st = 2*subtile + kstep  -> key0 = 16*st
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        const int keyA = st * 16 + 4 * lh + tr_q;
-        const int col = dt * 32 + tr_dcol;     // bf16 column inside the 64-dim row
-        const int offA = v_off(keyA, col >> 3) + (col & 7) * 2;
-        const int offB = v_off(keyA + 8, col >> 3) + (col & 7) * 2;
+        const int offA = (dt == 0 ? tr_base0 : tr_base1) + st * 16 * 128;   // keys 16*st + 4*lh + tr_q (+0..3)
+        const int offB = offA + 8 * 128;                                     // keys + 8
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
             (__attribute__((address_space(3))) s16x4*)(sv + offA));
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -192,13 +207,16 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(const MvdAttnArgs a) {
         if (dt == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[st], o0, 0, 0, 0);
         else         o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[st], o1, 0, 0, 0);
       }
+      // row sums on the matrix pipe (the softmax VALU stream is the bottleneck at head_dim 64): a V^T tile whose
+      // row 0 is all ones accumulates sum_k P[k][q] -- of the SAME bf16-rounded P the numerator uses -- into ol[0]
+      ol = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones_frag, pb[st], ol, 0, 0, 0);
     }
     if (more) store_tile(cur ^ 1);
     __syncthreads();
   }
 
   // ---- epilogue: O[q][d] = O^T / l ; lane holds d = 32*dt + (r&3) + 8*(r>>2) + 4*lh
-  const float inv = 1.0f / pair_sum(l_run);
+  const float inv = 1.0f / pair_sum(ol[0]);   // lanes 32..63 hold row 4 of the ones tile (= 0) in ol[0]
   if (qrow < nq) {
     bf16_t* orow = op + (size_t)qrow * P.ldo;
 #pragma unroll
@@ -250,7 +268,9 @@ int mvd_attention_pick_nw(const MvdAttnArgs& a) {
   int maxq = 0;
   for (int i = 0; i < a.nprob; ++i) maxq = a.p[i].nq > maxq ? a.p[i].nq : maxq;
   const long heads_total = (long)a.heads * a.batch * a.nprob;
-  if (maxq >= 256 && heads_total * ((maxq + 255) / 256) >= 512) return 3;
+  static const int force = [] { const char* e = getenv("MVD_ATTN_NW"); return e ? atoi(e) : -1; }();
+  if (force >= 0) return force;
+  // 4-wave workgroups (128 queries) fit three per CU at 144 VGPRs; the 8-wave shape only fits one
   if (maxq >= 128 && heads_total * ((maxq + 127) / 128) >= 512) return 2;
   if (maxq >= 64) return 1;
   return 0;

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(C::NT, C::MIN_WAVES) void gemm_kernel(const MvdGemm
         for (int i = 0; i < C::TM; ++i) acc[i][j] = bv;
       }
     }
-    if (a.rowvec) {
+    if (C::TN <= 5 && a.rowvec) {          // (GEGLU-only configs never carry a row vector)
 #pragma unroll
       for (int i = 0; i < C::TM; ++i) {
         int m = m0 + wm * C::WTM + i * 16 + fr;
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(C::NT, C::MIN_WAVES) void gemm_kernel(const MvdGemm
       const int m = m0 + wm * C::WTM + i * 16 + fr;
       const bool live = m < a.M;
       const int mc = live ? m : a.M - 1;
-      if (!a.geglu) {
+      if (!(C::TN > 5 || a.geglu)) {       // configs with TN > 5 exist for GEGLU only
         u32x2 res_r[C::TN];
         if (a.res) {
           const bf16_t* rp = a.res + (size_t)mc * a.ldres + nb;
@@ -334,6 +334,23 @@ __global__ __launch_bounds__(C::NT, C::MIN_WAVES) void gemm_kernel(const MvdGemm
             for (int j = 0; j < C::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], a0, acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int j = 0; j < C::TN; ++j) acc[i + 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], a1, acc[i + 1][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          continue;
+        } else if constexpr (C::TN > 5) {
+          // wide wave tile (160 columns, used for GEGLU where value/gate tiles must pair up): stream the W fragments
+          bf16x8 af[C::TM];
+#pragma unroll
+          for (int i = 0; i < C::TM; ++i)
+            af[i] = *reinterpret_cast<const bf16x8*>(sa + swz_off(wm * C::WTM + i * 16 + fr, s2 * 4 + fq));
+#pragma unroll
+          for (int j = 0; j < C::TN; j += 2) {
+            const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(sb + swz_off(wn * C::WTN + j * 16 + fr, s2 * 4 + fq));
+            const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(sb + swz_off(wn * C::WTN + (j + 1) * 16 + fr, s2 * 4 + fq));
+#pragma unroll
+            for (int i = 0; i < C::TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, af[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < C::TM; ++i) acc[i][j + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, af[i], acc[i][j + 1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
           }
           continue;
@@ -447,8 +464,9 @@ using C3 = Cfg<128, 128, 2, 2>;
 using C4 = Cfg<128, 64, 2, 2>;
 using C5 = Cfg<64, 64, 2, 2>;
 using C7 = Cfg<256, 320, 2, 4>;   // wave tile 128x80: 49 FLOP per LDS-read byte instead of 36
-// (config 6 was a three-stage 256x160 experiment: no gain, the kernel is LDS-read bound, not load-latency bound)
-const CfgInfo kCfgs[] = {{256, 160, 0}, {256, 128, 1}, {128, 160, 0}, {128, 128, 1}, {128, 64, 1}, {64, 64, 1}, {0, 1 << 30, 0}, {256, 320, 0}};
+using C6 = Cfg<256, 320, 4, 2>;   // wave tile 64x160 (even number of 16-column tiles: GEGLU value/gate pairs)
+// (a three-stage 256x160 experiment gave no gain: the kernel is LDS-read bound, not load-latency bound)
+const CfgInfo kCfgs[] = {{256, 160, 0}, {256, 128, 1}, {128, 160, 0}, {128, 128, 1}, {128, 64, 1}, {64, 64, 1}, {256, 320, 1}, {256, 320, 0}};
 constexpr int kNumCfgs = 8;
 
 }  // namespace
@@ -462,9 +480,10 @@ int mvd_gemm_pick_config(const MvdGemmArgs& a) {
   // 256x320 tile with 128x80 wave tiles (49 FLOP per LDS-read byte): the kernel is LDS-bandwidth bound, so this
   // is the fastest shape whenever its tile grid -- times a split-K of up to 8 -- can occupy the 256 CUs
   static const int use7 = [] { const char* e = getenv("MVD_GEMM_BIG"); return e ? atoi(e) : 1; }();
-  if (use7 && !a.geglu && a.N % 320 == 0 && a.M >= 1024) {
+  if (use7 && a.N % 320 == 0 && a.M >= 1024) {
     const long t7 = (long)((a.M + 255) / 256) * (a.N / 320);
-    if (t7 >= 200 || (a.Ktot / 64 >= 16 && t7 * 8 >= 200)) return 7;
+    if (a.geglu) { if (t7 >= 200) return 6; }
+    else if (t7 >= 200 || (a.Ktot / 64 >= 16 && t7 * 8 >= 200)) return 7;
   }
   static const int order[] = {2, 3, 4, 5};
   int cfg = -1, first_valid = -1;
@@ -525,6 +544,9 @@ int mvd_launch_gemm(const MvdGemmArgs& a, hipStream_t s, int force_cfg) {
     case 2: return launch_cfg<C2>(a, s, glds);
     case 3: return launch_cfg<C3>(a, s, glds);
     case 4: return launch_cfg<C4>(a, s, glds);
+    case 6:
+      if (!a.geglu || a.seg[0].mode != MVD_A_DENSE || a.splitk > 1) { mvd_set_error("gemm: tile config 6 is GEGLU-only"); return -1; }
+      return launch_mode2<C6, 0, true, false>(a, s);
     case 7: return launch_cfg<C7>(a, s, true);
     default: return launch_cfg<C5>(a, s, glds);
   }

@@ -90,10 +90,10 @@ def test_linear_epilogues(ops):
     close(got32, a.float() @ w[:, :k1].float().T + bias, tol=1e-4, what="linear fp32 out")
 
 
-@pytest.mark.parametrize("cfg", [-1, 1, 3, 4, 5, 9, 11, 12, 13])
+@pytest.mark.parametrize("cfg", [-1, 1, 3, 4, 5, 6, 9, 11, 12, 13])
 def test_linear_geglu(ops, cfg):
     from mvd_amd.packing import _geglu_rows
-    m, c = 200, 128
+    m, c = 300, 320
     a = rnd(m, c, seed=1)
     w = rnd(8 * c, c, scale=1 / math.sqrt(c), seed=2)
     bias = rnd(8 * c, seed=3, dtype=torch.float32)
