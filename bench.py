@@ -192,8 +192,19 @@ def main():
             dom = max(mf, key=lambda k: mf[k]["ms"])
             c = mf[dom]
             ach = c["flops"] / (c["ms"] * 1e-3) / 1e12
+            # HBM bytes per launch of that kernel class from the committed rocprofv3 --pmc passes of this command
+            # (FETCH_SIZE x2 + WRITE_SIZE, gfx950 corrections; tools/pmc_summary.py) -- PMC cannot run inside bench.py
+            traffic = None
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+                if args.workload == "cfg4" and not args.cached and dom in pmc:
+                    traffic = round(pmc[dom]["hbm_bytes_per_launch"])
+            except (OSError, ValueError):
+                pass
             roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA / 1e12,
-                        "unit": "TFLOP/s", "frac": round(ach * 1e12 / PEAK_BF16_MFMA, 4), "traffic": None,
+                        "unit": "TFLOP/s", "frac": round(ach * 1e12 / PEAK_BF16_MFMA, 4), "traffic": traffic,
+                        "traffic_source": "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" if traffic else None,
+                        "flops_per_launch": round(c["flops"] / c["launches"]),
                         "avg_launch_us": round(c["ms"] * 1e3 / c["launches"], 2), "launches_per_step": c["launches"] // nprof,
                         "share_of_step_time": round(c["ms"] / tot_ms, 3),
                         "measured_over": f"{nprof} profiled steps after the timed region (HIP events on the launch stream)",

@@ -483,7 +483,8 @@ int mvd_gemm_pick_config(const MvdGemmArgs& a) {
   if (use7 && a.N % 320 == 0 && a.M >= 1024) {
     const long t7 = (long)((a.M + 255) / 256) * (a.N / 320);
     if (a.geglu) { if (t7 >= 200) return 6; }
-    else if (t7 >= 200 || (a.Ktot / 64 >= 16 && t7 * 8 >= 200)) return 7;
+    // (a split of 2 at most: the fp32 partials of deeper splits cost more than the bigger tile gains)
+    else if (t7 >= 200 || (a.Ktot / 64 >= 16 && t7 * 2 >= 200)) return 7;
   }
   static const int order[] = {2, 3, 4, 5};
   int cfg = -1, first_valid = -1;
@@ -560,17 +561,11 @@ int mvd_gemm_pick_splitk(const MvdGemmArgs& a) {
   if (cfg < 0) return 1;
   const long tiles = (long)((a.M + kCfgs[cfg].bm - 1) / kCfgs[cfg].bm) * (a.N / kCfgs[cfg].bn);
   const int nkt = a.Ktot / 64;
-  if (cfg == 7) {   // one 147 KB workgroup per CU: aim for 256 work items
-    if (tiles >= 200 || nkt < 16) return 1;
-    long s7 = (256 + tiles - 1) / tiles;
-    if (s7 > nkt / 8) s7 = nkt / 8;
-    if (s7 > 8) s7 = 8;
-    return s7 < 2 ? 1 : (int)s7;
-  }
+  if (cfg == 7) return (tiles >= 200 || nkt < 16) ? 1 : 2;   // one 147 KB workgroup per CU
   if (tiles >= 256 || nkt < 16) return 1;
-  long s = 512 / tiles;
+  long s = 512 / tiles;                                       // two workgroups per CU
   if (s > nkt / 8) s = nkt / 8;
-  if (s > 8) s = 8;
+  if (s > 4) s = 4;                                           // partial-sum traffic grows with the split
   return s < 2 ? 1 : (int)s;
 }
 

@@ -131,33 +131,51 @@ __global__ void f32_to_bf16_kernel(const float* __restrict__ x, long n, bf16_t* 
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = f2bf(x[i]);
 }
 
-// skinny linear: one wave per output feature; batch processed in chunks of 8
+// skinny linear (camera / time MLPs, fp32 activations): one wave per output feature, the weight row is read
+// ONCE per 32 batch rows (it was the dominant cost at batch 32), 16-byte loads when K % 4 == 0
 template <bool WBF16>
 __global__ __launch_bounds__(256) void skinny_linear_kernel(const float* __restrict__ x, int ldx, int batch, int k,
                                                              const void* __restrict__ wv, const float* __restrict__ bias,
                                                              int n, int act_in, float* __restrict__ y, int ldy) {
+  constexpr int BC = 32;
   const int lane = threadIdx.x & 63;
   const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (o >= n) return;
-  for (int b0 = 0; b0 < batch; b0 += 8) {
-    float acc[8];
+  const bool vec = !WBF16 && (k & 3) == 0 && (ldx & 3) == 0;
+  for (int b0 = 0; b0 < batch; b0 += BC) {
+    float acc[BC];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    for (int kk = lane; kk < k; kk += 64) {
-      float wgt;
-      if (WBF16) wgt = bf2f(reinterpret_cast<const bf16_t*>(wv)[(size_t)o * k + kk]);
-      else wgt = reinterpret_cast<const float*>(wv)[(size_t)o * k + kk];
+    for (int j = 0; j < BC; ++j) acc[j] = 0.f;
+    if (vec) {
+      const float* wr = reinterpret_cast<const float*>(wv) + (size_t)o * k;
+      for (int kk = lane * 4; kk < k; kk += 256) {
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + kk);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if (b0 + j < batch) {
-          float xv = x[(size_t)(b0 + j) * ldx + kk];
-          if (act_in == 1) xv = silu_f(xv);
-          acc[j] = fmaf(xv, wgt, acc[j]);
+        for (int j = 0; j < BC; ++j) {
+          if (b0 + j < batch) {
+            f32x4 x4 = *reinterpret_cast<const f32x4*>(x + (size_t)(b0 + j) * ldx + kk);
+            if (act_in == 1) { x4[0] = silu_f(x4[0]); x4[1] = silu_f(x4[1]); x4[2] = silu_f(x4[2]); x4[3] = silu_f(x4[3]); }
+            acc[j] = fmaf(x4[0], w4[0], fmaf(x4[1], w4[1], fmaf(x4[2], w4[2], fmaf(x4[3], w4[3], acc[j]))));
+          }
+        }
+      }
+    } else {
+      for (int kk = lane; kk < k; kk += 64) {
+        float wgt;
+        if (WBF16) wgt = bf2f(reinterpret_cast<const bf16_t*>(wv)[(size_t)o * k + kk]);
+        else wgt = reinterpret_cast<const float*>(wv)[(size_t)o * k + kk];
+#pragma unroll
+        for (int j = 0; j < BC; ++j) {
+          if (b0 + j < batch) {
+            float xv = x[(size_t)(b0 + j) * ldx + kk];
+            if (act_in == 1) xv = silu_f(xv);
+            acc[j] = fmaf(xv, wgt, acc[j]);
+          }
         }
       }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < BC; ++j) {
       if (b0 + j < batch) {
         const float t = wave_sum(acc[j]);
         if (lane == 0) y[(size_t)(b0 + j) * ldy + o] = t + (bias ? bias[o] : 0.f);
