@@ -68,7 +68,7 @@ int mvd_launch_attention(const MvdAttnArgs& a, hipStream_t s);
 // ---------------------------------------------------------------- normalisation
 // GroupNorm over NHWC with optional 2-source channel concat; y = gn(x)*gamma+beta, optional SiLU.
 // ws: fp32 scratch of at least batch*MVD_GN_MAXCHUNK*groups*2 floats.
-#define MVD_GN_MAXCHUNK 64
+#define MVD_GN_MAXCHUNK 256
 int mvd_launch_groupnorm(const bf16_t* x0, const bf16_t* x1, int c0, int c1, int batch, int hw, int groups,
                          float eps, const float* gamma, const float* beta, int silu, bf16_t* y, float* ws,
                          hipStream_t s);

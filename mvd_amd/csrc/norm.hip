@@ -69,17 +69,25 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
   float* s_rstd = sh + groups;
   float* s_a = sh + 2 * groups;
   float* s_b = s_a + C;
-  if (threadIdx.x < groups) {
+  {
+    // fixed-order (deterministic) reduction of the partial sums: 8 lanes per group, then an xor-shuffle tree
+    const int g = threadIdx.x >> 3, part = threadIdx.x & 7;
     float s = 0.f, q = 0.f;
-    for (int ck = 0; ck < nchunk_stats; ++ck) {
-      s += ws[(((size_t)b * nchunk_stats + ck) * groups + threadIdx.x) * 2];
-      q += ws[(((size_t)b * nchunk_stats + ck) * groups + threadIdx.x) * 2 + 1];
+    if (g < groups) {
+      for (int ck = part; ck < nchunk_stats; ck += 8) {
+        s += ws[(((size_t)b * nchunk_stats + ck) * groups + g) * 2];
+        q += ws[(((size_t)b * nchunk_stats + ck) * groups + g) * 2 + 1];
+      }
     }
-    const float n = (float)hw * (float)cg;
-    const float mean = s / n;
-    const float var = fmaxf(q / n - mean * mean, 0.f);
-    s_mean[threadIdx.x] = mean;
-    s_rstd[threadIdx.x] = rsqrtf(var + eps);
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    if (g < groups && part == 0) {
+      const float n = (float)hw * (float)cg;
+      const float mean = s / n;
+      const float var = fmaxf(q / n - mean * mean, 0.f);
+      s_mean[g] = mean;
+      s_rstd[g] = rsqrtf(var + eps);
+    }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -241,7 +249,7 @@ static int check_launch(const char* what) {
 int mvd_launch_groupnorm(const bf16_t* x0, const bf16_t* x1, int c0, int c1, int batch, int hw, int groups, float eps,
                          const float* gamma, const float* beta, int silu, bf16_t* y, float* ws, hipStream_t s) {
   const int C = c0 + c1;
-  if (!x0 || (c1 && !x1) || !y || !ws || !gamma || !beta || batch <= 0 || hw <= 0 || groups <= 0 || groups > 128 ||
+  if (!x0 || (c1 && !x1) || !y || !ws || !gamma || !beta || batch <= 0 || hw <= 0 || groups <= 0 || groups > 32 ||
       (C % groups) || (c0 % 8) || (c1 % 8) || C > 8192) {
     mvd_set_error("groupnorm: bad arguments (c0=%d c1=%d batch=%d hw=%d groups=%d)", c0, c1, batch, hw, groups);
     return -1;
@@ -250,15 +258,23 @@ int mvd_launch_groupnorm(const bf16_t* x0, const bf16_t* x1, int c0, int c1, int
   if (vec > 1024) { mvd_set_error("groupnorm: C=%d too wide", C); return -1; }
   const int R = vec >= 256 ? 1 : 256 / vec;
   const int threads = ((vec * R + 63) / 64) * 64;
+  // enough workgroups to cover the chip even at batch 1: >= ~512 blocks when the map is large enough,
+  // at least 8 rows per chunk
   int nchunk = hw / 64;
+  if ((long)nchunk * batch < 512) nchunk = (512 + batch - 1) / batch;
+  if (nchunk > hw / 8) nchunk = hw / 8;
   nchunk = nchunk < 1 ? 1 : (nchunk > MVD_GN_MAXCHUNK ? MVD_GN_MAXCHUNK : nchunk);
   const int rpc = (hw + nchunk - 1) / nchunk;
   nchunk = (hw + rpc - 1) / rpc;
   const size_t sh1 = (size_t)R * C * 2 * sizeof(float);
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, batch), dim3(threads), sh1, s, x0, x1, c0, c1, hw, groups, rpc, R, ws);
   if (int r = check_launch("gn_stats")) return r;
-  // apply: ~16K elements per block
-  int rows_per_blk = (16384 + C - 1) / C;
+  // apply: ~16K elements per block, fewer when that would leave CUs idle (small batch)
+  long per_blk = 16384;
+  const long total_el = (long)batch * hw * C;
+  if (total_el / per_blk < 1024) per_blk = total_el / 1024 < 2048 ? 2048 : total_el / 1024;
+  int rows_per_blk = (int)((per_blk + C - 1) / C);
+  if (rows_per_blk < 1) rows_per_blk = 1;
   if (rows_per_blk > hw) rows_per_blk = hw;
   const int nblk = (hw + rows_per_blk - 1) / rows_per_blk;
   const size_t sh2 = (size_t)(2 * groups + 2 * C) * sizeof(float);

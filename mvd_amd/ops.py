@@ -84,7 +84,7 @@ def groupnorm(x, gamma, beta, groups=32, eps=1e-5, silu=False, x2=None):
     B, hw, c0 = x.shape
     c1 = x2.shape[2] if x2 is not None else 0
     y = torch.empty(B, hw, c0 + c1, device=x.device, dtype=torch.bfloat16)
-    ws = torch.empty(B * 64 * groups * 2, device=x.device, dtype=torch.float32)
+    ws = torch.empty(B * 256 * groups * 2, device=x.device, dtype=torch.float32)   # MVD_GN_MAXCHUNK partial sums
     L.call("mvd_op_groupnorm", _p(x), _p(x2), c0, c1, B, hw, groups, float(eps), _p(gamma), _p(beta), int(silu), _p(y),
            _p(ws), _s())
     return y
