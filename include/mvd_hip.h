@@ -143,6 +143,14 @@ int mvd_op_nhwc_to_nchw(const void* x, int batch, int hw, int c, float* y, void*
 int mvd_op_f32_to_bf16(const float* x, int64_t n, void* y, void* stream);
 int mvd_gemm_num_configs(void);
 
+/* ---- denoising-loop helpers either side of the UNet, fp32 latents ------ */
+/* DDPM ancestral step, coefficients from mvd_amd/scheduler.py (diffusers DDPMScheduler.step algebra):
+ *   x0 = c0*model_out + c1*sample ; out = c2*x0 + c3*sample + sigma*noise.   Replaces pipeline.py:161. */
+int mvd_op_ddpm_step(const float* model_out, const float* sample, const float* noise, float c0, float c1, float c2,
+                     float c3, float sigma, float* out, int64_t n, void* stream);
+/* classifier-free guidance combine of [uncond | cond] stacked on the batch dim (pipeline.py:156-158) */
+int mvd_op_cfg_combine(const float* uncond_cond, float guidance_scale, float* out, int64_t n_half, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,6 +76,9 @@ _SIGS = {
     "mvd_op_nhwc_to_nchw": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mvd_op_f32_to_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "mvd_gemm_num_configs": (C.c_int, []),
+    "mvd_op_ddpm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float,
+                                   C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
+    "mvd_op_cfg_combine": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS)

@@ -133,6 +133,24 @@ def conv_out(x, w, bias):
     return y
 
 
+def ddpm_step(model_out, sample, noise, c0, c1, c2, c3, sigma):
+    """fp32: x0 = c0*model_out + c1*sample ; prev = c2*x0 + c3*sample + sigma*noise (noise may be None iff sigma == 0)."""
+    assert model_out.dtype == torch.float32 and sample.dtype == torch.float32
+    out = torch.empty_like(sample)
+    L.call("mvd_op_ddpm_step", _p(model_out), _p(sample), _p(noise), float(c0), float(c1), float(c2), float(c3),
+           float(sigma), _p(out), sample.numel(), _s())
+    return out
+
+
+def cfg_combine(uncond_cond, guidance_scale):
+    """(2B, ...) fp32 [uncond | cond] -> (B, ...) uncond + g*(cond - uncond)."""
+    assert uncond_cond.dtype == torch.float32 and uncond_cond.shape[0] % 2 == 0
+    out = torch.empty((uncond_cond.shape[0] // 2,) + tuple(uncond_cond.shape[1:]), device=uncond_cond.device,
+                      dtype=torch.float32)
+    L.call("mvd_op_cfg_combine", _p(uncond_cond), float(guidance_scale), _p(out), out.numel(), _s())
+    return out
+
+
 def nchw_to_nhwc(x, scale=None, shift=None):
     B, c, H, W = x.shape
     y = torch.empty(B, H, W, c, device=x.device, dtype=torch.bfloat16)
