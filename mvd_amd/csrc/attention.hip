@@ -8,23 +8,25 @@
 // Structure (per wave: 32 query rows; per workgroup: NW waves sharing K/V tiles in LDS):
 //   S^T = K . Q^T   v_mfma_f32_32x32x16_bf16, A = K rows from LDS (ds_read_b128, XOR
 //                   swizzle), B = Q fragments held in registers for the whole kernel.
-//                   The result has the QUERY on the lane and 32 of the 64 keys of the KV
-//                   tile in the lane's registers -> row max / row sum are in-register
-//                   reductions plus one v_permlane32_swap with the partner half-wave.
+//                   The result has the QUERY on the lane and half of the keys of the KV
+//                   tile in the lane's registers -> row max is an in-register reduction
+//                   plus one v_permlane32_swap with the partner half-wave.
 //   O^T += V^T . P^T  the S^T accumulator (converted to bf16) is directly the B operand
 //                   of the second MFMA (k-index permutation of the accumulator layout is
 //                   matched on the V side); V^T fragments come from the row-major V tile
 //                   through ds_read_b64_tr_b16 (hardware transpose read).
-//   online softmax in exp2 domain with the softmax scale folded into one v_fma.
-// K/V tiles (64 keys) are double buffered in LDS; global loads for tile t+1 are issued
-// before the MFMAs of tile t and written after them.
+//   softmax         exp2 domain, scale folded into one v_fma, raw v_exp_f32; the rescale of O
+//                   is DEFERRED until some row's max grew by > 2^6; the denominators are
+//                   accumulated on the matrix pipe by a V^T tile whose row 0 is all ones.
+// KV tiles hold NSUB x 32 keys: 64 by default.  The 128-key variant halves the per-tile fixed costs
+// (barrier, max reduction tree, rescale test, loader address math) but loses a wave per SIMD and
+// measured slower (profiles/r01_probe_attention_kv128.log); it is kept behind MVD_ATTN_KV128=1.  K/V tiles are double buffered in LDS;
+// global loads for tile t+1 are issued before the MFMAs of tile t and written after them.
 #include <stdlib.h>
 #include "kernels.h"
 
 namespace {
 
-constexpr int KV_TILE = 64;
-constexpr int TILE_BYTES = KV_TILE * 128;  // 64 keys x 64 dims x 2 B
 constexpr float NEG_BIG = -1.0e30f;
 constexpr float RESCALE_LOG2 = 6.0f;   // defer the online-softmax rescale while P stays below 2^6
 
@@ -46,12 +48,15 @@ MVD_DEVINL float pair_other(float x, float& own) {
 MVD_DEVINL float pair_max(float x) { float o; const float p = pair_other(x, o); return fmaxf(o, p); }
 MVD_DEVINL float pair_sum(float x) { float o; const float p = pair_other(x, o); return o + p; }
 
-// 2nd launch-bound = waves per SIMD: three 4-wave workgroups (12 waves) stay co-resident per CU
-template <int NW>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void attn_kernel(const MvdAttnArgs a) {
+// NW waves x 32 queries per workgroup, KV tile = NSUB * 32 keys.
+// 2nd launch-bound = waves per SIMD (register budget for the intended residency).
+template <int NW, int NSUB>
+__global__ __launch_bounds__(64 * NW, (NW == 4 && NSUB == 2) ? 3 : 2) void attn_kernel(const MvdAttnArgs a) {
   constexpr int NT = 64 * NW;
   constexpr int QB = 32 * NW;
-  constexpr int LD_IT = (KV_TILE * 8) / NT;  // 16-byte chunks per thread per tile
+  constexpr int KV_TILE = 32 * NSUB;
+  constexpr int TILE_BYTES = KV_TILE * 128;         // keys x 64 dims x 2 B
+  constexpr int LD_IT = (KV_TILE * 8) / NT;         // 16-byte chunks per thread per tile
   static_assert((KV_TILE * 8) % NT == 0, "tile must divide over threads");
   __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];  // K0 K1 V0 V1
 
@@ -79,9 +84,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void attn_kernel(const Mv
   for (int ks = 0; ks < 4; ++ks)
     qf[ks] = *reinterpret_cast<const bf16x8*>(qp + (size_t)qrow_c * P.ldq + ks * 16 + lh * 8);
 
-  // loader mapping: chunk id -> (key row, 16-byte chunk)
+  // loader mapping: chunk id -> (key row, 16-byte chunk); one thread's chunks are NT/8 rows apart; when that is a
+  // multiple of 16 they share the swizzle pattern and their LDS offsets differ by constants
   const int ld_kc = tid & 7;
   const int ld_row = tid >> 3;
+  const int ld_koff = k_off(ld_row, ld_kc), ld_voff = v_off(ld_row, ld_kc);
+  const bf16_t* ld_kp = kp + (size_t)ld_row * P.ldk + ld_kc * 8;
+  const bf16_t* ld_vp = vp + (size_t)ld_row * P.ldv + ld_kc * 8;
   u32x4 rk[LD_IT], rv[LD_IT];
   auto load_tile = [&](int kb) {
 #pragma unroll
@@ -89,8 +98,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void attn_kernel(const Mv
       const int key = kb * KV_TILE + ld_row + i * (NT / 8);
       u32x4 zk = {0u, 0u, 0u, 0u}, zv = {0u, 0u, 0u, 0u};
       if (key < nk) {
-        zk = *reinterpret_cast<const u32x4*>(kp + (size_t)key * P.ldk + ld_kc * 8);
-        zv = *reinterpret_cast<const u32x4*>(vp + (size_t)key * P.ldv + ld_kc * 8);
+        zk = *reinterpret_cast<const u32x4*>(ld_kp + (size_t)(kb * KV_TILE + i * (NT / 8)) * P.ldk);
+        zv = *reinterpret_cast<const u32x4*>(ld_vp + (size_t)(kb * KV_TILE + i * (NT / 8)) * P.ldv);
       }
       rk[i] = zk; rv[i] = zv;
     }
@@ -100,9 +109,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void attn_kernel(const Mv
     unsigned char* sv = smem + (2 + st) * TILE_BYTES;
 #pragma unroll
     for (int i = 0; i < LD_IT; ++i) {
-      const int r = ld_row + i * (NT / 8);
-      *reinterpret_cast<u32x4*>(sk + k_off(r, ld_kc)) = rk[i];
-      *reinterpret_cast<u32x4*>(sv + v_off(r, ld_kc)) = rv[i];
+      if constexpr ((NT / 8) % 16 == 0) {
+        *reinterpret_cast<u32x4*>(sk + ld_koff + i * (NT / 8) * 128) = rk[i];
+        *reinterpret_cast<u32x4*>(sv + ld_voff + i * (NT / 8) * 128) = rv[i];
+      } else {   // single-wave workgroups: rows 8 apart change the K swizzle
+        *reinterpret_cast<u32x4*>(sk + k_off(ld_row + i * (NT / 8), ld_kc)) = rk[i];
+        *reinterpret_cast<u32x4*>(sv + v_off(ld_row + i * (NT / 8), ld_kc)) = rv[i];
+      }
     }
   };
 
@@ -127,7 +140,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void attn_kernel(const Mv
   // +16*st and +8, so the two d tiles differ by an XOR of 64 bytes and everything else is an immediate.
   const int tr_base0 = v_off(4 * lh + tr_q, tr_dcol >> 3) + (tr_dcol & 7) * 2;
   const int tr_base1 = tr_base0 ^ 64;
-  int k_base[4];   // K row lq, chunk (2*ks + lh) ^ swizzle(lq); rows lq+32 share the swizzle
+  int k_base[4];   // K row lq, chunk (2*ks + lh) ^ swizzle(lq); rows lq+32*t share the swizzle
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) k_base[ks] = k_off(lq, ks * 2 + lh);
 
@@ -138,30 +151,34 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void attn_kernel(const Mv
     const unsigned char* sk = smem + cur * TILE_BYTES;
     const unsigned char* sv = smem + (2 + cur) * TILE_BYTES;
 
-    // ---- S^T = K.Q^T for the two 32-key sub tiles
-    f32x16 s0 = {}, s1 = {};
+    // ---- S^T = K.Q^T for the NSUB 32-key sub tiles
+    f32x16 s[NSUB];
+#pragma unroll
+    for (int t = 0; t < NSUB; ++t) s[t] = f32x16{};
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(sk + k_base[ks]);
-      const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(sk + k_base[ks] + 32 * 128);
-      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[ks], s0, 0, 0, 0);
-      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[ks], s1, 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NSUB; ++t) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + k_base[ks] + t * 32 * 128);
+        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t], 0, 0, 0);
+      }
     }
     // ---- mask keys beyond nk (only the last tile can be ragged)
     if (kb * KV_TILE + KV_TILE > nk) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kb * KV_TILE + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (key >= nk) s0[r] = NEG_BIG;
-        if (key + 32 >= nk) s1[r] = NEG_BIG;
-      }
+      for (int t = 0; t < NSUB; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kb * KV_TILE + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (key >= nk) s[t][r] = NEG_BIG;
+        }
     }
-    // ---- online softmax (this lane: one query, 32 of the 64 keys; partner lane^32 has the rest)
-    float mx = s0[0];
+    // ---- online softmax (this lane: one query, half of the tile's keys; partner lane^32 has the rest)
+    float mx = s[0][0];
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s0[r]);
+    for (int t = 0; t < NSUB; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s1[r]);
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
     mx = pair_max(mx);
     // Deferred rescale: the running max is only raised (and O / the row sums rescaled) when some row's max
     // grew by more than RESCALE_LOG2 in the exp2 domain; otherwise P is taken against the old max and is bounded
@@ -176,23 +193,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void attn_kernel(const Mv
     }
     const float mc = m_run * c;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], c, -mc));   // raw v_exp_f32
-      s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], c, -mc));
-    }
+    for (int t = 0; t < NSUB; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[t][r] = __builtin_amdgcn_exp2f(fmaf(s[t][r], c, -mc));   // raw v_exp_f32
 
-    // ---- P^T as bf16 B operands: k-step s (16 keys) of sub tile t = accumulator regs 8s..8s+7
-    bf16x8 pb[4];
+    // ---- O^T += V^T . P^T, 16 keys (one k-step) at a time.  P^T as bf16 B operand: k-step st of sub tile t =
+    //      accumulator regs 8*(st&1).. of s[st>>1]; A operand element j of lane (d, h) = V[16*st + 8*(j>>2) + 4h + (j&3)][d]
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      pb[0][j] = (__bf16)s0[j];
-      pb[1][j] = (__bf16)s0[8 + j];
-      pb[2][j] = (__bf16)s1[j];
-      pb[3][j] = (__bf16)s1[8 + j];
-    }
-    // ---- O^T += V^T . P^T ; A operand element j of lane (d, h) = V[key0 + 8*(j>>2) + 4h + (j&3)][d]
+    for (int st = 0; st < 2 * NSUB; ++st) {
+      bf16x8 pb;
 #pragma unroll
-    for (int st = 0; st < 4; ++st) {          // st = 2*subtile + kstep  -> key0 = 16*st
+      for (int j = 0; j < 8; ++j) pb[j] = (__bf16)s[st >> 1][8 * (st & 1) + j];
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
         const int offA = (dt == 0 ? tr_base0 : tr_base1) + st * 16 * 128;   // keys 16*st + 4*lh + tr_q (+0..3)
@@ -204,12 +215,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void attn_kernel(const Mv
         typedef __attribute__((ext_vector_type(8))) short s16x8;
         const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         const bf16x8 vf = __builtin_bit_cast(bf16x8, both);
-        if (dt == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[st], o0, 0, 0, 0);
-        else         o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[st], o1, 0, 0, 0);
+        if (dt == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, o0, 0, 0, 0);
+        else         o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, o1, 0, 0, 0);
       }
       // row sums on the matrix pipe (the softmax VALU stream is the bottleneck at head_dim 64): a V^T tile whose
       // row 0 is all ones accumulates sum_k P[k][q] -- of the SAME bf16-rounded P the numerator uses -- into ol[0]
-      ol = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones_frag, pb[st], ol, 0, 0, 0);
+      ol = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones_frag, pb, ol, 0, 0, 0);
     }
     if (more) store_tile(cur ^ 1);
     __syncthreads();
@@ -229,11 +240,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void attn_kernel(const Mv
   }
 }
 
-template <int NW>
+template <int NW, int NSUB>
 int launch_nw(const MvdAttnArgs& a, int maxq, hipStream_t s) {
   const int qb = 32 * NW;
   dim3 grid((maxq + qb - 1) / qb, a.heads, a.batch * a.nprob);
-  hipLaunchKernelGGL(attn_kernel<NW>, grid, dim3(64 * NW), 0, s, a);
+  hipLaunchKernelGGL((attn_kernel<NW, NSUB>), grid, dim3(64 * NW), 0, s, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { mvd_set_error("attention launch: %s", hipGetErrorString(e)); return -3; }
   return 0;
@@ -245,7 +256,7 @@ int mvd_attention_pick_nw(const MvdAttnArgs& a);
 
 int mvd_launch_attention(const MvdAttnArgs& a, hipStream_t s) {
   if (a.nprob < 1 || a.nprob > 2 || a.batch <= 0 || a.heads <= 0) { mvd_set_error("attention: bad problem count/batch/heads"); return -1; }
-  int maxq = 0;
+  int maxq = 0, mink = 1 << 30;
   for (int i = 0; i < a.nprob; ++i) {
     const MvdAttnProblem& p = a.p[i];
     if (!p.q || !p.k || !p.v || !p.o || p.nq <= 0 || p.nk <= 0) { mvd_set_error("attention: null pointer or empty problem %d", i); return -1; }
@@ -253,24 +264,29 @@ int mvd_launch_attention(const MvdAttnArgs& a, hipStream_t s) {
     if (((uintptr_t)p.q | (uintptr_t)p.k | (uintptr_t)p.v) & 15 || ((uintptr_t)p.o & 7)) { mvd_set_error("attention: misaligned pointer in problem %d", i); return -1; }
     if ((p.bsq % 8) || (p.bsk % 8) || (p.bsv % 8) || (p.bso % 4)) { mvd_set_error("attention: bad batch strides in problem %d", i); return -1; }
     maxq = p.nq > maxq ? p.nq : maxq;
+    mink = p.nk < mink ? p.nk : mink;
   }
+  // 128-key tiles are an experiment switch only (env MVD_ATTN_KV128=1): at 197 VGPRs / 64 KB LDS they run two
+  // waves per SIMD instead of three and measured 3-4 % SLOWER than 64-key tiles on every UNet shape
+  // (profiles/r01_probe_attention_kv128.log)
+  static const int kv128 = [] { const char* e = getenv("MVD_ATTN_KV128"); return e ? atoi(e) : 0; }();
+  const bool big = kv128 != 0 && mink >= 256;
   switch (mvd_attention_pick_nw(a)) {
-    case 3: return launch_nw<8>(a, maxq, s);
-    case 2: return launch_nw<4>(a, maxq, s);
-    case 1: return launch_nw<2>(a, maxq, s);
-    default: return launch_nw<1>(a, maxq, s);
+    case 3: return launch_nw<8, 2>(a, maxq, s);
+    case 2: return big ? launch_nw<4, 4>(a, maxq, s) : launch_nw<4, 2>(a, maxq, s);
+    case 1: return launch_nw<2, 2>(a, maxq, s);
+    default: return launch_nw<1, 2>(a, maxq, s);
   }
 }
 
-// log2 of the waves per workgroup: enough workgroups to fill 256 CUs, prefer 8 waves (256 queries),
-// shrink for small problems
+// log2 of the waves per workgroup: enough workgroups to fill 256 CUs; 4-wave workgroups (128 queries) fit
+// three per CU at ~165 VGPRs, the 8-wave shape only one
 int mvd_attention_pick_nw(const MvdAttnArgs& a) {
   int maxq = 0;
   for (int i = 0; i < a.nprob; ++i) maxq = a.p[i].nq > maxq ? a.p[i].nq : maxq;
   const long heads_total = (long)a.heads * a.batch * a.nprob;
   static const int force = [] { const char* e = getenv("MVD_ATTN_NW"); return e ? atoi(e) : -1; }();
   if (force >= 0) return force;
-  // 4-wave workgroups (128 queries) fit three per CU at 144 VGPRs; the 8-wave shape only fits one
   if (maxq >= 128 && heads_total * ((maxq + 127) / 128) >= 512) return 2;
   if (maxq >= 64) return 1;
   return 0;

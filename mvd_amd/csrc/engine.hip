@@ -67,7 +67,8 @@ struct mvd_engine {
   int tkv_total = 0;
   // optional per-kernel-class profiling (HIP events on the launch stream)
   bool prof = false;
-  struct ProfRec { int cls; double flops; double bytes; hipEvent_t e0, e1; };
+  struct ProfRec { int cls; double flops; double bytes; hipEvent_t e0, e1; int M, N, K, tag; };
+  int prof_M = 0, prof_N = 0, prof_K = 0, prof_tag = 0;   // shape of the launch being recorded (per-shape dump)
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
   hipEvent_t get_event() {
@@ -122,7 +123,7 @@ struct Ctx {
     hipEventRecord(e0, s);
     const int r = launch();
     hipEventRecord(e1, s);
-    e->prof_recs.push_back({cls, flops, bytes, e0, e1});
+    e->prof_recs.push_back({cls, flops, bytes, e0, e1, e->prof_M, e->prof_N, e->prof_K, e->prof_tag});
     return r;
   }
   int gemm(MvdGemmArgs& g) {
@@ -136,6 +137,7 @@ struct Ctx {
     int r = 0;
     if (!dry) {
       const double fl = 2.0 * g.M * (double)g.N * g.Ktot;
+      e->prof_M = g.M; e->prof_N = g.N; e->prof_K = g.Ktot; e->prof_tag = g.seg[0].mode * 100 + g.geglu * 10 + (S > 1 ? S : 0);
       r = profiled(e->prof ? mvd_gemm_pick_config(g) : 0, fl, 0.0, [&] { return mvd_launch_gemm(g, s); });
       if (!r && S > 1) r = mvd_launch_splitk_reduce(g, s);
     }
@@ -187,6 +189,7 @@ struct Ctx {
     if (err) return err; if (dry) return 0;
     double fl = 0;
     for (int i = 0; i < a.nprob; ++i) fl += 4.0 * a.batch * a.heads * (double)a.p[i].nq * a.p[i].nk * 64;
+    e->prof_M = a.p[0].nq; e->prof_N = a.p[0].nk; e->prof_K = a.heads; e->prof_tag = 1000 + a.nprob;
     return profiled(e->prof ? 8 + mvd_attention_pick_nw(a) : 8, fl, 0.0, [&] { return mvd_launch_attention(a, s); });
   }
 };
@@ -792,6 +795,19 @@ int mvd_engine_profile_summary(mvd_engine_t* e, int cap, int* cls, int* launches
     while (j < n && cls[j] != r.cls) ++j;
     if (j == n) { if (n == cap) continue; cls[n] = r.cls; launches[n] = 0; ms[n] = 0; flops[n] = 0; bytes[n] = 0; ++n; }
     launches[j] += 1; ms[j] += t; flops[j] += r.flops; bytes[j] += r.bytes;
+  }
+  if (getenv("MVD_PROFILE_SHAPES")) {   // per-shape table on stderr (measurement aid)
+    struct Acc { int cls, M, N, K, tag, n; double ms, fl; };
+    std::vector<Acc> v;
+    for (auto& r : e->prof_recs) {
+      if (r.flops <= 0) continue;
+      float t = 0.f; hipEventElapsedTime(&t, r.e0, r.e1);
+      size_t j = 0;
+      while (j < v.size() && !(v[j].cls == r.cls && v[j].M == r.M && v[j].N == r.N && v[j].K == r.K && v[j].tag == r.tag)) ++j;
+      if (j == v.size()) v.push_back({r.cls, r.M, r.N, r.K, r.tag, 0, 0.0, 0.0});
+      v[j].n++; v[j].ms += t; v[j].fl += r.flops;
+    }
+    for (auto& x : v) fprintf(stderr, "shape cls=%d M=%d N=%d K=%d tag=%d launches=%d ms=%.3f tflops=%.0f\n", x.cls, x.M, x.N, x.K, x.tag, x.n, x.ms, x.fl / x.ms / 1e9);
   }
   e->prof_recs.clear(); e->ev_used = 0;
   return n;

@@ -10,7 +10,7 @@ def time_fn(fn, iters=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
 rnd = lambda *s: torch.randn(*s, device="cuda").to(torch.bfloat16)
-for name, B, h, n, nk in [("L0 self", 32, 5, 4096, 4096)]:
+for name, B, h, n, nk in [("L0 self", 32, 5, 4096, 4096), ("L1 self", 32, 10, 1024, 1024), ("L2 self", 32, 20, 256, 256), ("L0 text", 32, 5, 4096, 77)]:
     q, k, v = rnd(B, n, h * 64), rnd(B, nk, h * 64), rnd(B, nk, h * 64)
     ms = time_fn(lambda: ops.attention(q, k, v, h))
-    print(f"dbg={os.environ.get('MVD_ATTN_DEBUG','0')} NW={os.environ.get('MVD_ATTN_NW','auto')} {name}: {ms*1e3:8.1f} us {4.0*B*h*n*nk*64/ms/1e9:7.0f} TF", flush=True)
+    print(f"kv128={os.environ.get('MVD_ATTN_KV128','auto')} NW={os.environ.get('MVD_ATTN_NW','auto')} {name}: {ms*1e3:8.1f} us {4.0*B*h*n*nk*64/ms/1e9:7.0f} TF", flush=True)
