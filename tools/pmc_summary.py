@@ -8,7 +8,7 @@ import collections, csv, glob, json, sys
 CLASSES = {
     "gemm_256x320": "Cfg<256, 320, 2, 4>", "gemm_256x320_geglu": "Cfg<256, 320, 4, 2>", "gemm_128x160": "Cfg<128, 160, 2, 2>",
     "gemm_128x128": "Cfg<128, 128, 2, 2>", "gemm_128x64": "Cfg<128, 64, 2, 2>", "gemm_64x64": "Cfg<64, 64, 2, 2>",
-    "attn_4wave": "attn_kernel<4>", "attn_8wave": "attn_kernel<8>", "attn_2wave": "attn_kernel<2>", "attn_1wave": "attn_kernel<1>",
+    "attn_4wave": "attn_kernel<4,", "attn_8wave": "attn_kernel<8,", "attn_2wave": "attn_kernel<2,", "attn_1wave": "attn_kernel<1,",
     "groupnorm": "gn_", "layernorm": "ln_kernel",
 }
 
