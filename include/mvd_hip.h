@@ -125,6 +125,8 @@ int mvd_op_linear(const void* a, const void* a2, int k1, int k2, const void* w, 
 int mvd_op_conv3x3(const void* x, int batch, int in_h, int in_w, int cin, int stride, int upsample, const void* w,
                    const float* bias, const float* rowvec, int ld_rowvec, const void* res, const void* sc, const void* sc2,
                    int sc_c1, int sc_c2, void* out, int cout, int force_cfg, int splitk, float* splitk_ws, void* stream);
+/* softmax(scale * q.k^T).v per head of 64 channels.  scale == 0 selects the engine's form: q is already multiplied
+ * by softmax_scale * log2(e) (the packed to_q / to_q_ref weight rows carry that factor, DESIGN.md "Weight slots"). */
 int mvd_op_attention(const void* q, const void* k, const void* v, void* o, int batch, int heads, int nq, int nk, int ldq,
                      int ldk, int ldv, int ldo, float scale, void* stream);
 int mvd_op_groupnorm(const void* x0, const void* x1, int c0, int c1, int batch, int hw, int groups, float eps,

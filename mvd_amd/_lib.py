@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmvd_hip.so")
+# MVD_HIP_LIB selects another build of the same library (A/B measurements: tools/build_variant.py)
+LIB_PATH = os.environ.get("MVD_HIP_LIB") or os.path.join(HERE, "libmvd_hip.so")
 
 MVD_MAX_LEVELS = 4
 MVD_USE_CAMERA, MVD_USE_IMAGE, MVD_REUSE_REF, MVD_KEEP_FEATURES = 1, 2, 4, 8

@@ -50,7 +50,10 @@ MVD_DEVINL float pair_sum(float x) { float o; const float p = pair_other(x, o); 
 
 // NW waves x 32 queries per workgroup, KV tile = NSUB * 32 keys.
 // 2nd launch-bound = waves per SIMD (register budget for the intended residency).
-template <int NW, int NSUB>
+// PRE: Q arrives pre-multiplied by softmax_scale * log2(e) (folded into the to_q weights by the host packing), so
+// the QK^T accumulator is already the exp2-domain score; it is STARTED at -running_max (C operand of the first
+// MFMA), so the exponent argument leaves the matrix pipe ready-made and the per-score v_fma disappears.
+template <int NW, int NSUB, bool PRE>
 __global__ __launch_bounds__(64 * NW, (NW == 4 && NSUB == 2) ? 3 : 2) void attn_kernel(const MvdAttnArgs a) {
   constexpr int NT = 64 * NW;
   constexpr int QB = 32 * NW;
@@ -92,16 +95,23 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && NSUB == 2) ? 3 : 2) void attn_
   const bf16_t* ld_kp = kp + (size_t)ld_row * P.ldk + ld_kc * 8;
   const bf16_t* ld_vp = vp + (size_t)ld_row * P.ldv + ld_kc * 8;
   u32x4 rk[LD_IT], rv[LD_IT];
+  const int ldk = P.ldk, ldv = P.ldv;
   auto load_tile = [&](int kb) {
+    const int k0 = kb * KV_TILE;
+    if (k0 + KV_TILE <= nk) {          // full tile (uniform branch): per-lane base + uniform offset
 #pragma unroll
-    for (int i = 0; i < LD_IT; ++i) {
-      const int key = kb * KV_TILE + ld_row + i * (NT / 8);
-      u32x4 zk = {0u, 0u, 0u, 0u}, zv = {0u, 0u, 0u, 0u};
-      if (key < nk) {
-        zk = *reinterpret_cast<const u32x4*>(ld_kp + (size_t)(kb * KV_TILE + i * (NT / 8)) * P.ldk);
-        zv = *reinterpret_cast<const u32x4*>(ld_vp + (size_t)(kb * KV_TILE + i * (NT / 8)) * P.ldv);
+      for (int i = 0; i < LD_IT; ++i) {
+        rk[i] = *reinterpret_cast<const u32x4*>(ld_kp + (size_t)(k0 + i * (NT / 8)) * ldk);
+        rv[i] = *reinterpret_cast<const u32x4*>(ld_vp + (size_t)(k0 + i * (NT / 8)) * ldv);
       }
-      rk[i] = zk; rv[i] = zv;
+    } else {                           // ragged last tile: rows past nk re-read row nk-1 (their scores are masked,
+#pragma unroll                         // so P = 0 meets a finite V row)
+      for (int i = 0; i < LD_IT; ++i) {
+        int key = k0 + ld_row + i * (NT / 8);
+        key = key < nk ? key : nk - 1;
+        rk[i] = *reinterpret_cast<const u32x4*>(kp + (size_t)key * ldk + ld_kc * 8);
+        rv[i] = *reinterpret_cast<const u32x4*>(vp + (size_t)key * ldv + ld_kc * 8);
+      }
     }
   };
   auto store_tile = [&](int st) {
@@ -124,8 +134,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && NSUB == 2) ? 3 : 2) void attn_
   bf16x8 ones_frag;
 #pragma unroll
   for (int j = 0; j < 8; ++j) ones_frag[j] = (lq == 0) ? (__bf16)1.0f : (__bf16)0.0f;
-  float m_run = NEG_BIG;
-  const float c = a.scale * 1.4426950408889634f;  // scale * log2(e)
+  float m_run = PRE ? 0.f : NEG_BIG;
+  const float c = a.scale * 1.4426950408889634f;  // scale * log2(e)   (unused when PRE)
+  f32x16 negm = {};              // PRE: -m_run in every register (C operand that starts each score tile)
 
   const int nkb = (nk + KV_TILE - 1) / KV_TILE;
   load_tile(0);
@@ -154,13 +165,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && NSUB == 2) ? 3 : 2) void attn_
     // ---- S^T = K.Q^T for the NSUB 32-key sub tiles
     f32x16 s[NSUB];
 #pragma unroll
-    for (int t = 0; t < NSUB; ++t) s[t] = f32x16{};
-#pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
       for (int t = 0; t < NSUB; ++t) {
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + k_base[ks] + t * 32 * 128);
-        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t], 0, 0, 0);
+        if (ks == 0) s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0], PRE ? negm : f32x16{}, 0, 0, 0);
+        else         s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t], 0, 0, 0);
       }
     }
     // ---- mask keys beyond nk (only the last tile can be ragged)
@@ -183,19 +193,44 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && NSUB == 2) ? 3 : 2) void attn_
     // Deferred rescale: the running max is only raised (and O / the row sums rescaled) when some row's max
     // grew by more than RESCALE_LOG2 in the exp2 domain; otherwise P is taken against the old max and is bounded
     // by 2^RESCALE_LOG2 (bf16 keeps its relative precision, the accumulators are fp32).  Wave-uniform branch.
-    if (!__all((mx - m_run) * c <= RESCALE_LOG2)) {
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-      m_run = m_new;
+    if constexpr (PRE) {
+      // s holds score - m_run (exp2 domain).  The first tile always sets the running max (m_run starts at 0, so a row
+      // whose scores are all far below zero would otherwise underflow every P).
+      if (kb == 0 || !__all(mx <= RESCALE_LOG2)) {
+        const float delta = kb == 0 ? mx : fmaxf(mx, 0.f);     // m_new - m_run
+        if (kb != 0) {
+          const float alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-      ol[0] *= alpha;                       // row sums live in row 0 of the "ones" tile
+          for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+          ol[0] *= alpha;
+        }
+        m_run += delta;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[r] = -m_run;
+#pragma unroll
+        for (int t = 0; t < NSUB; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[t][r] -= delta;
+      }
+#pragma unroll
+      for (int t = 0; t < NSUB; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[t][r] = __builtin_amdgcn_exp2f(s[t][r]);
+    } else {
+      if (!__all((mx - m_run) * c <= RESCALE_LOG2)) {
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        ol[0] *= alpha;                       // row sums live in row 0 of the "ones" tile
+      }
+      const float mc = m_run * c;
+#pragma unroll
+      for (int t = 0; t < NSUB; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[t][r] = __builtin_amdgcn_exp2f(fmaf(s[t][r], c, -mc));   // raw v_exp_f32
     }
-    const float mc = m_run * c;
-#pragma unroll
-    for (int t = 0; t < NSUB; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[t][r] = __builtin_amdgcn_exp2f(fmaf(s[t][r], c, -mc));   // raw v_exp_f32
 
     // ---- O^T += V^T . P^T, 16 keys (one k-step) at a time.  P^T as bf16 B operand: k-step st of sub tile t =
     //      accumulator regs 8*(st&1).. of s[st>>1]; A operand element j of lane (d, h) = V[16*st + 8*(j>>2) + 4h + (j&3)][d]
@@ -244,7 +279,8 @@ template <int NW, int NSUB>
 int launch_nw(const MvdAttnArgs& a, int maxq, hipStream_t s) {
   const int qb = 32 * NW;
   dim3 grid((maxq + qb - 1) / qb, a.heads, a.batch * a.nprob);
-  hipLaunchKernelGGL((attn_kernel<NW, NSUB>), grid, dim3(64 * NW), 0, s, a);
+  if (a.prescaled) hipLaunchKernelGGL((attn_kernel<NW, NSUB, true>), grid, dim3(64 * NW), 0, s, a);
+  else             hipLaunchKernelGGL((attn_kernel<NW, NSUB, false>), grid, dim3(64 * NW), 0, s, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { mvd_set_error("attention launch: %s", hipGetErrorString(e)); return -3; }
   return 0;
@@ -270,7 +306,7 @@ int mvd_launch_attention(const MvdAttnArgs& a, hipStream_t s) {
   // waves per SIMD instead of three and measured 3-4 % SLOWER than 64-key tiles on every UNet shape
   // (profiles/r01_probe_attention_kv128.log)
   static const int kv128 = [] { const char* e = getenv("MVD_ATTN_KV128"); return e ? atoi(e) : 0; }();
-  const bool big = kv128 != 0 && mink >= 256;
+  const bool big = kv128 != 0 && mink >= 256 && !a.prescaled;
   switch (mvd_attention_pick_nw(a)) {
     case 3: return launch_nw<8, 2>(a, maxq, s);
     case 2: return big ? launch_nw<4, 4>(a, maxq, s) : launch_nw<4, 2>(a, maxq, s);

@@ -294,7 +294,7 @@ struct UNetPass {
     bf16_t* h = c.talloc<bf16_t>((size_t)M * C);
     CHECK(c.linear(n0, nullptr, C, 0, M, c.WB(key + ".proj_in.w", (int64_t)C * C), c.WF(key + ".proj_in.b", C), C, nullptr, 0, h, C));
     bf16_t* ln = n0;  // reuse
-    const float scale = 0.125f;
+    const float scale = 0.125f;   // (folded, with log2 e, into the packed to_q / to_q_ref rows: a.prescaled)
     bf16_t* o_self = c.talloc<bf16_t>((size_t)M * C);
     bf16_t* o_ref = ad ? c.talloc<bf16_t>((size_t)M * C) : nullptr;
     const bf16_t* rkv = ad ? c.e->refkv[feat_idx] : nullptr;
@@ -309,7 +309,7 @@ struct UNetPass {
       CHECK(c.layernorm(h, M, C, c.WF(key + ".ln1.g", C), c.WF(key + ".ln1.b", C), ln));
       CHECK(c.linear(ln, nullptr, C, 0, M, c.WB(key + ".attn1.qkv.w", (int64_t)(packed ? 4 : 3) * C * C), nullptr, nq, nullptr, 0, qkv, nq));
       MvdAttnArgs a; memset(&a, 0, sizeof(a));
-      a.batch = B_; a.heads = heads; a.scale = scale; a.nprob = ad ? 2 : 1;
+      a.batch = B_; a.heads = heads; a.scale = scale; a.prescaled = 1; a.nprob = ad ? 2 : 1;
       a.p[0] = {qkv, qkv + C, qkv + 2 * C, o_self, nq, nq, nq, C, (int64_t)hw * nq, (int64_t)hw * nq, (int64_t)hw * nq, (int64_t)hw * C, hw, hw};
       if (ad) a.p[1] = {qkv + 3 * C, rkv, rkv + C, o_ref, nq, 4 * C, 4 * C, C, (int64_t)hw * nq, (int64_t)ref_nk * 4 * C, (int64_t)ref_nk * 4 * C, (int64_t)hw * C, hw, ref_nk};
       CHECK(c.attention(a));
@@ -326,7 +326,7 @@ struct UNetPass {
       CHECK(c.layernorm(h, M, C, c.WF(key + ".ln2.g", C), c.WF(key + ".ln2.b", C), ln));
       CHECK(c.linear(ln, nullptr, C, 0, M, c.WB(key + ".attn2.q.w", (int64_t)(packed ? 2 : 1) * C * C), nullptr, nq, nullptr, 0, q2, nq));
       MvdAttnArgs a; memset(&a, 0, sizeof(a));
-      a.batch = B_; a.heads = heads; a.scale = scale; a.nprob = ad ? 2 : 1;
+      a.batch = B_; a.heads = heads; a.scale = scale; a.prescaled = 1; a.nprob = ad ? 2 : 1;
       a.p[0] = {q2, kv2, kv2 + C, o_self, nq, ldkv, ldkv, C, (int64_t)hw * nq, (int64_t)L * ldkv, (int64_t)L * ldkv, (int64_t)hw * C, hw, L};
       if (ad) a.p[1] = {q2 + C, rkv + 2 * C, rkv + 3 * C, o_ref, nq, 4 * C, 4 * C, C, (int64_t)hw * nq, (int64_t)ref_nk * 4 * C, (int64_t)ref_nk * 4 * C, (int64_t)hw * C, hw, ref_nk};
       CHECK(c.attention(a));
@@ -910,6 +910,7 @@ int mvd_op_attention(const void* q, const void* k, const void* v, void* o, int b
                      int ldk, int ldv, int ldo, float scale, void* stream) {
   MvdAttnArgs a; memset(&a, 0, sizeof(a));
   a.nprob = 1; a.batch = batch; a.heads = heads; a.scale = scale;
+  a.prescaled = scale == 0.f;   // q already carries softmax_scale * log2(e)
   a.p[0] = {(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, ldq, ldk, ldv, ldo,
             (int64_t)nq * ldq, (int64_t)nk * ldk, (int64_t)nk * ldv, (int64_t)nq * ldo, nq, nk};
   return mvd_launch_attention(a, (hipStream_t)stream);

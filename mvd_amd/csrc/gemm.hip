@@ -157,6 +157,7 @@ __global__ __launch_bounds__(C::NT, C::MIN_WAVES) void gemm_kernel(const MvdGemm
 #pragma unroll
       for (int i = 0; i < C::A_IT; ++i) {
         const bf16_t* p = base + (size_t)a_m[i] * ld + col;
+        if (GLDS && (a.dbg & 4)) continue;   // measurement aid: no A traffic
         if (GLDS) glds16(p, sa + (wave_chunk0 + i * C::NT) * 16);
         else ra[i] = *reinterpret_cast<const u32x4*>(p);
       }
@@ -166,6 +167,7 @@ __global__ __launch_bounds__(C::NT, C::MIN_WAVES) void gemm_kernel(const MvdGemm
       const int row = lrow + i * C::ROWS_PER_IT;
       if (C::B_CHUNKS % C::NT == 0 || row < C::BN) {
         const bf16_t* p = a.W + (size_t)(ld_n0 + row) * a.ldw + lk * 64 + kc * 8;
+        if (GLDS && (a.dbg & 8)) continue;   // measurement aid: no W traffic
         if (GLDS) glds16(p, sb + (wave_chunk0 + i * C::NT) * 16);
         else rb[i] = *reinterpret_cast<const u32x4*>(p);
       }
@@ -326,6 +328,7 @@ __global__ __launch_bounds__(C::NT, C::MIN_WAVES) void gemm_kernel(const MvdGemm
 #pragma unroll
           for (int j = 0; j < C::TN; ++j)
             wf[j] = *reinterpret_cast<const bf16x8*>(sb + swz_off(wn * C::WTN + j * 16 + fr, s2 * 4 + fq));
+#ifdef MVD_GEMM_NO_SWP
 #pragma unroll
           for (int i = 0; i < C::TM; i += 2) {
             const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(sa + swz_off(wm * C::WTM + i * 16 + fr, s2 * 4 + fq));
@@ -336,6 +339,28 @@ __global__ __launch_bounds__(C::NT, C::MIN_WAVES) void gemm_kernel(const MvdGemm
             for (int j = 0; j < C::TN; ++j) acc[i + 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], a1, acc[i + 1][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
           }
+#else
+          // software pipeline: the next pair of A fragments is read while the MFMAs of the current pair run
+          bf16x8 a0 = *reinterpret_cast<const bf16x8*>(sa + swz_off(wm * C::WTM + fr, s2 * 4 + fq));
+          bf16x8 a1 = *reinterpret_cast<const bf16x8*>(sa + swz_off(wm * C::WTM + 16 + fr, s2 * 4 + fq));
+#pragma unroll
+          for (int i = 0; i < C::TM; i += 2) {
+            bf16x8 n0 = a0, n1 = a1;
+            if (i + 2 < C::TM) {
+              n0 = *reinterpret_cast<const bf16x8*>(sa + swz_off(wm * C::WTM + (i + 2) * 16 + fr, s2 * 4 + fq));
+              n1 = *reinterpret_cast<const bf16x8*>(sa + swz_off(wm * C::WTM + (i + 3) * 16 + fr, s2 * 4 + fq));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int j = 0; j < C::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], a0, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < C::TN; ++j) acc[i + 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], a1, acc[i + 1][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = n0; a1 = n1;
+          }
+#endif
           continue;
         } else if constexpr (C::TN > 5) {
           // wide wave tile (160 columns, used for GEGLU where value/gate tiles must pair up): stream the W fragments

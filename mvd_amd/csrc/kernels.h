@@ -62,6 +62,7 @@ struct MvdAttnArgs {
   int nprob;
   int batch, heads;
   float scale;                    // softmax scale (1/sqrt(64))
+  int prescaled;                  // 1: q is already multiplied by scale*log2(e) (host-folded into to_q); scale unused
 };
 int mvd_launch_attention(const MvdAttnArgs& a, hipStream_t s);
 

@@ -66,7 +66,8 @@ def conv3x3(x, w_packed, bias=None, stride=1, upsample=False, rowvec=None, res=N
 
 
 def attention(q, k, v, heads, scale=0.125):
-    """q: (B,Nq,heads*64) bf16, k/v: (B,Nk,heads*64); row strides may exceed heads*64 (views of fused buffers)."""
+    """q: (B,Nq,heads*64) bf16, k/v: (B,Nk,heads*64); row strides may exceed heads*64 (views of fused buffers).
+    scale=0 selects the engine's form: q already multiplied by 64^-0.5 * log2(e) (packing.QSCALE)."""
     _bf16(q, k, v)
     B, nq, _ = q.shape
     nk = k.shape[1]

@@ -5,9 +5,9 @@ One-time host work (torch is used as plumbing for the permutes / casts).  Slot l
 
   conv          [Cout][Cin/64][ky][kx][64] bf16  (K = 9*Cin; channel-slice major, taps inner)
   resnet conv2  conv2 | conv_shortcut(1x1) concatenated along K, biases summed
-  attn1.qkv     [to_q; to_k; to_v; (to_q_ref)]            rows concatenated
+  attn1.qkv     [QSCALE*to_q; to_k; to_v; (QSCALE*to_q_ref)]   rows concatenated; QSCALE = 64^-0.5 * log2(e)
   attn1.out     [to_out.0 | ref_scale * to_out_ref.0]     K concatenated, bias = b + ref_scale*b_ref
-  attn2.q       [to_q; (to_q_ref)]     text_kv: every attn2 site's [to_k; to_v] stacked in module order
+  attn2.q       [QSCALE*to_q; (QSCALE*to_q_ref)]     text_kv: every attn2 site's [to_k; to_v] stacked in module order
   ref_kv        [to_k_ref(self); to_v_ref(self); to_k_ref(cross); to_v_ref(cross)]
   ff1           GEGLU rows interleaved in blocks of 16: (16 value rows, 16 gate rows)
   temb_proj     every resnet's time_emb_proj stacked in module order (one GEMM per forward)
@@ -19,6 +19,9 @@ from typing import Dict
 import torch
 
 from .config import UNetConfig
+
+# softmax scale of a 64-wide head times log2(e): folded into every query projection (see pack_unet)
+QSCALE = 64 ** -0.5 * 1.4426950408889634
 
 
 def _bf(t: torch.Tensor, device) -> torch.Tensor:
@@ -93,8 +96,11 @@ def pack_unet(sd: Dict[str, torch.Tensor], cfg: UNetConfig, device, adapter: boo
             out[f"{key}.ln{i}.g"] = _f32(sd[f"{b}.norm{i}.weight"], device)
             out[f"{key}.ln{i}.b"] = _f32(sd[f"{b}.norm{i}.bias"], device)
         f = lambda k: sd[k].detach().float()  # noqa: E731
-        qkv = [f(f"{b}.attn1.to_q.weight"), f(f"{b}.attn1.to_k.weight"), f(f"{b}.attn1.to_v.weight")]
-        q2 = [f(f"{b}.attn2.to_q.weight")]
+        # every query projection carries the softmax scale and log2(e): the attention kernel then works in the exp2
+        # domain without a per-score multiply (attn_kernel<.., PRE>); the factor is applied in fp32 before the bf16
+        # rounding of the weights
+        qkv = [QSCALE * f(f"{b}.attn1.to_q.weight"), f(f"{b}.attn1.to_k.weight"), f(f"{b}.attn1.to_v.weight")]
+        q2 = [QSCALE * f(f"{b}.attn2.to_q.weight")]
         for a in ("attn1", "attn2"):
             wo, bo = f(f"{b}.{a}.to_out.0.weight"), f(f"{b}.{a}.to_out.0.bias")
             if adapter:
@@ -106,8 +112,8 @@ def pack_unet(sd: Dict[str, torch.Tensor], cfg: UNetConfig, device, adapter: boo
             out[f"{key}.{a}.out.b"] = _f32(bo, device)
         if adapter:
             p1, p2 = f"{b}.attn1.processor", f"{b}.attn2.processor"
-            qkv.append(f(f"{p1}.to_q_ref.weight"))
-            q2.append(f(f"{p2}.to_q_ref.weight"))
+            qkv.append(QSCALE * f(f"{p1}.to_q_ref.weight"))
+            q2.append(QSCALE * f(f"{p2}.to_q_ref.weight"))
             out[f"{key}.ref_kv.w"] = _bf(torch.cat([f(f"{p1}.to_k_ref.weight"), f(f"{p1}.to_v_ref.weight"),
                                                     f(f"{p2}.to_k_ref.weight"), f(f"{p2}.to_v_ref.weight")], 0), device)
         out[f"{key}.attn1.qkv.w"] = _bf(torch.cat(qkv, 0), device)

@@ -92,8 +92,13 @@ def test_packing_layouts(tiny_model):
     k = "down_blocks.0.attentions.0"
     b = f"{k}.transformer_blocks.0"
     assert packed[f"{k}.attn1.qkv.w"].shape == (4 * C, C)
+    from mvd_amd.packing import QSCALE   # query projections carry 64^-0.5 * log2(e)
     torch.testing.assert_close(packed[f"{k}.attn1.qkv.w"][3 * C:].float(),
-                               sd[f"{b}.attn1.processor.to_q_ref.weight"].to(torch.bfloat16).float())
+                               (QSCALE * sd[f"{b}.attn1.processor.to_q_ref.weight"].float()).to(torch.bfloat16).float())
+    torch.testing.assert_close(packed[f"{k}.attn1.qkv.w"][:C].float(),
+                               (QSCALE * sd[f"{b}.attn1.to_q.weight"].float()).to(torch.bfloat16).float())
+    torch.testing.assert_close(packed[f"{k}.attn1.qkv.w"][C:2 * C].float(),
+                               sd[f"{b}.attn1.to_k.weight"].to(torch.bfloat16).float())
     wo = packed[f"{k}.attn2.out.w"]
     assert wo.shape == (C, 2 * C)
     torch.testing.assert_close(wo[:, C:].float(), (0.3 * sd[f"{b}.attn2.processor.to_out_ref.0.weight"]).to(torch.bfloat16).float())

@@ -182,6 +182,28 @@ def test_attention(ops, B, heads, nq, nk):
     close(got, want, tol=2 ** -6, what=f"attention {B}x{heads}x{nq}x{nk}")
 
 
+@pytest.mark.parametrize("B,heads,nq,nk,shift", [
+    (2, 5, 256, 256, 0.0), (1, 2, 64, 77, 0.0), (3, 1, 16, 16, 0.0), (2, 2, 144, 144, 0.0), (1, 20, 64, 32, 0.0),
+    (1, 5, 1024, 1024, 0.0), (1, 1, 4, 4, 0.0),
+    (1, 2, 160, 200, -40.0),   # every score far below zero: the first tile must still set the running max
+    (1, 2, 160, 200, 25.0),    # large positive scores
+])
+def test_attention_prescaled(ops, B, heads, nq, nk, shift):
+    """Engine form: q carries softmax_scale*log2(e) (folded into to_q by the packing); kernel works in the exp2 domain."""
+    from mvd_amd.packing import QSCALE
+    C = heads * 64
+    q, k, v = rnd(B, nq, C, seed=1), rnd(B, nk, C, seed=2), rnd(B, nk, C, seed=3)
+    if shift:   # add a constant direction so that q.k is shifted by about `shift` (pre-softmax, natural-log units)
+        k = (k.float() + 1.0).to(torch.bfloat16)
+        q = (q.float() + shift * 8.0 / 64.0).to(torch.bfloat16)
+    qs = (q.float() * QSCALE).to(torch.bfloat16)          # what the scaled to_q GEMM would emit
+    sp = lambda t, n: t.float().view(B, n, heads, 64).transpose(1, 2)  # noqa: E731
+    # reference on the SAME rounded operand: softmax over ln2 * (qs . k)
+    want = F.scaled_dot_product_attention(sp(qs, nq) * 0.6931471805599453, sp(k, nk), sp(v, nk), scale=1.0)
+    got = ops.attention(qs.cuda(), k.cuda(), v.cuda(), heads, scale=0.0)
+    close(got, want.transpose(1, 2).reshape(B, nq, C), tol=2 ** -6, what=f"prescaled attention {B}x{heads}x{nq}x{nk} shift {shift}")
+
+
 def test_attention_strided_views_and_spike(ops):
     """Fused-QKV strides, plus a forced online-softmax rescale (one key spikes late in the sequence)."""
     B, heads, n = 2, 2, 320

@@ -10,6 +10,8 @@ TILES = {0: (256, 160), 1: (256, 128), 2: (128, 160), 3: (128, 128), 4: (128, 64
 TILES.update({k + 8: v for k, v in list(TILES.items())})
 TILES[7] = (256, 320)
 TILES[6] = (256, 320)
+if os.environ.get('TUNE_CFGS'):
+    TILES = {int(c): TILES[int(c)] for c in os.environ['TUNE_CFGS'].split(',')}
 
 def time_fn(fn, iters=5):
     fn(); torch.cuda.synchronize()
