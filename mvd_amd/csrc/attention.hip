@@ -92,26 +92,36 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && NSUB == 2) ? 3 : 2) void attn_
   const int ld_kc = tid & 7;
   const int ld_row = tid >> 3;
   const int ld_koff = k_off(ld_row, ld_kc), ld_voff = v_off(ld_row, ld_kc);
-  const bf16_t* ld_kp = kp + (size_t)ld_row * P.ldk + ld_kc * 8;
-  const bf16_t* ld_vp = vp + (size_t)ld_row * P.ldv + ld_kc * 8;
-  u32x4 rk[LD_IT], rv[LD_IT];
+  // Loads use a UNIFORM 64-bit base (scalar registers, advanced per tile) plus a loop-invariant 32-bit per-lane byte
+  // offset, so a full tile costs no vector address arithmetic; the ragged last tile recomputes the offsets with the
+  // row index clamped to nk-1 (those keys' scores are masked, so P = 0 meets a finite V row).
   const int ldk = P.ldk, ldv = P.ldv;
+  const unsigned ld_ko = ((unsigned)ld_row * (unsigned)ldk + ld_kc * 8) * 2u;
+  const unsigned ld_vo = ((unsigned)ld_row * (unsigned)ldv + ld_kc * 8) * 2u;
+  const char* kp_b = reinterpret_cast<const char*>(kp);
+  const char* vp_b = reinterpret_cast<const char*>(vp);
+  u32x4 rk[LD_IT], rv[LD_IT];
   auto load_tile = [&](int kb) {
     const int k0 = kb * KV_TILE;
-    if (k0 + KV_TILE <= nk) {          // full tile (uniform branch): per-lane base + uniform offset
+    const bool full = k0 + KV_TILE <= nk;          // uniform
 #pragma unroll
-      for (int i = 0; i < LD_IT; ++i) {
-        rk[i] = *reinterpret_cast<const u32x4*>(ld_kp + (size_t)(k0 + i * (NT / 8)) * ldk);
-        rv[i] = *reinterpret_cast<const u32x4*>(ld_vp + (size_t)(k0 + i * (NT / 8)) * ldv);
-      }
-    } else {                           // ragged last tile: rows past nk re-read row nk-1 (their scores are masked,
-#pragma unroll                         // so P = 0 meets a finite V row)
-      for (int i = 0; i < LD_IT; ++i) {
+    for (int i = 0; i < LD_IT; ++i) {
+      const char* kb_s = kp_b;
+      const char* vb_s = vp_b;
+      unsigned ko, vo;
+      if (full) {
+        kb_s += (size_t)(k0 + i * (NT / 8)) * ldk * 2;
+        vb_s += (size_t)(k0 + i * (NT / 8)) * ldv * 2;
+        ko = ld_ko; vo = ld_vo;
+      } else {
         int key = k0 + ld_row + i * (NT / 8);
         key = key < nk ? key : nk - 1;
-        rk[i] = *reinterpret_cast<const u32x4*>(kp + (size_t)key * ldk + ld_kc * 8);
-        rv[i] = *reinterpret_cast<const u32x4*>(vp + (size_t)key * ldv + ld_kc * 8);
+        asm volatile("" : "+v"(key));              // keep this arithmetic inside the ragged branch
+        ko = ((unsigned)key * (unsigned)ldk + ld_kc * 8) * 2u;
+        vo = ((unsigned)key * (unsigned)ldv + ld_kc * 8) * 2u;
       }
+      rk[i] = *reinterpret_cast<const u32x4*>(kb_s + ko);
+      rv[i] = *reinterpret_cast<const u32x4*>(vb_s + vo);
     }
   };
   auto store_tile = [&](int st) {
