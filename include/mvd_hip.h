@@ -97,7 +97,7 @@ typedef struct {
 int mvd_unet_forward(mvd_engine_t* e, const mvd_forward_args_t* args, void* stream);
 
 /* Per-kernel-class timing with HIP events on the launch stream (measurement only; off by default).
- * classes: 0..5 GEMM/conv tile config, 8..11 attention (1,2,4,8 waves), 16 groupnorm, 17 layernorm. */
+ * classes: 0..7 GEMM/conv tile config, 12 the 128x320 tile, 8..11 attention (1,2,4,8 waves), 16 groupnorm, 17 layernorm. */
 int mvd_engine_set_profiling(mvd_engine_t* e, int enable);
 int mvd_engine_profile_summary(mvd_engine_t* e, int cap, int* cls, int* launches, double* ms, double* flops, double* bytes);
 

@@ -79,6 +79,7 @@ struct mvd_engine {
 
 // profiling classes: 0..5 = gemm tile config, 8..11 = attention NW (1,2,4,8), 16 groupnorm, 17 layernorm, 18 other
 int mvd_gemm_pick_config(const MvdGemmArgs& a);
+static inline int gemm_class(int cfg) { return cfg == 8 ? 12 : cfg; }   // profile classes 8..11 are the attention kernels
 int mvd_attention_pick_nw(const MvdAttnArgs& a);
 
 namespace {
@@ -138,7 +139,7 @@ struct Ctx {
     if (!dry) {
       const double fl = 2.0 * g.M * (double)g.N * g.Ktot;
       e->prof_M = g.M; e->prof_N = g.N; e->prof_K = g.Ktot; e->prof_tag = g.seg[0].mode * 100 + g.geglu * 10 + (S > 1 ? S : 0);
-      r = profiled(e->prof ? mvd_gemm_pick_config(g) : 0, fl, 0.0, [&] { return mvd_launch_gemm(g, s); });
+      r = profiled(e->prof ? gemm_class(mvd_gemm_pick_config(g)) : 0, fl, 0.0, [&] { return mvd_launch_gemm(g, s); });
       if (!r && S > 1) r = mvd_launch_splitk_reduce(g, s);
     }
     e->tmp.off = mark;

@@ -491,8 +491,10 @@ using C5 = Cfg<64, 64, 2, 2>;
 using C7 = Cfg<256, 320, 2, 4>;   // wave tile 128x80: 49 FLOP per LDS-read byte instead of 36
 using C6 = Cfg<256, 320, 4, 2>;   // wave tile 64x160 (even number of 16-column tiles: GEGLU value/gate pairs)
 // (a three-stage 256x160 experiment gave no gain: the kernel is LDS-read bound, not load-latency bound)
-const CfgInfo kCfgs[] = {{256, 160, 0}, {256, 128, 1}, {128, 160, 0}, {128, 128, 1}, {128, 64, 1}, {64, 64, 1}, {256, 320, 1}, {256, 320, 0}};
-constexpr int kNumCfgs = 8;
+using C8 = Cfg<128, 320, 2, 4>;   // wave tile 64x80: twice the tiles of C7 for M = 8192 (deep levels) -> no split-K
+const CfgInfo kCfgs[] = {{256, 160, 0}, {256, 128, 1}, {128, 160, 0}, {128, 128, 1}, {128, 64, 1}, {64, 64, 1}, {256, 320, 1}, {256, 320, 0},
+                         {128, 320, 0}};
+constexpr int kNumCfgs = 9;
 
 }  // namespace
 
@@ -505,11 +507,16 @@ int mvd_gemm_pick_config(const MvdGemmArgs& a) {
   // 256x320 tile with 128x80 wave tiles (49 FLOP per LDS-read byte): the kernel is LDS-bandwidth bound, so this
   // is the fastest shape whenever its tile grid -- times a split-K of up to 8 -- can occupy the 256 CUs
   static const int use7 = [] { const char* e = getenv("MVD_GEMM_BIG"); return e ? atoi(e) : 1; }();
+  // (128x320 tiles instead of a two-way split-K at M = 8192: measured 1 % SLOWER end to end -- the W slab is
+  //  re-fetched per 128 rows and the 64x80 wave tile reads more LDS per FLOP -- so it is an opt-in switch)
+  static const int use8 = [] { const char* e = getenv("MVD_GEMM_C8"); return e ? atoi(e) : 0; }();
   if (use7 && a.N % 320 == 0 && a.M >= 1024) {
     const long t7 = (long)((a.M + 255) / 256) * (a.N / 320);
     if (a.geglu) { if (t7 >= 200) return 6; }
     // (a split of 2 at most: the fp32 partials of deeper splits cost more than the bigger tile gains)
-    else if (t7 >= 200 || (a.Ktot / 64 >= 16 && t7 * 2 >= 200)) return 7;
+    else if (t7 >= 200) return 7;
+    else if (use8 && t7 * 2 >= 200) return 8;       // 128x320 tiles fill the chip without a split
+    else if (a.Ktot / 64 >= 16 && t7 * 2 >= 200) return 7;
   }
   static const int order[] = {2, 3, 4, 5};
   int cfg = -1, first_valid = -1;
@@ -561,7 +568,8 @@ int mvd_launch_gemm(const MvdGemmArgs& a, hipStream_t s, int force_cfg) {
   static const int dbg = [] { const char* e = getenv("MVD_GEMM_DEBUG"); return e ? atoi(e) : 0; }();
   if (dbg) const_cast<MvdGemmArgs&>(a).dbg = dbg;
   int cfg = force_cfg;
-  if (cfg >= 8) { glds = true; cfg -= 8; } else if (cfg >= 0 && cfg < 6) { glds = false; }
+  if (cfg == 14) { glds = true; cfg = 8; }       // force_cfg 14 = the 128x320 tile (LDS-DMA only)
+  else if (cfg >= 8) { glds = true; cfg -= 8; } else if (cfg >= 0 && cfg < 6) { glds = false; }
   if (cfg < 0) cfg = mvd_gemm_pick_config(a);
   if (cfg < 0 || cfg >= kNumCfgs || a.N % kCfgs[cfg].bn || (a.geglu && !kCfgs[cfg].tn_even)) { mvd_set_error("gemm: no tile config for N=%d geglu=%d cfg=%d", a.N, a.geglu, cfg); return -1; }
   switch (cfg) {
@@ -574,6 +582,7 @@ int mvd_launch_gemm(const MvdGemmArgs& a, hipStream_t s, int force_cfg) {
       if (!a.geglu || a.seg[0].mode != MVD_A_DENSE || a.splitk > 1) { mvd_set_error("gemm: tile config 6 is GEGLU-only"); return -1; }
       return launch_mode2<C6, 0, true, false>(a, s);
     case 7: return launch_cfg<C7>(a, s, true);
+    case 8: return launch_cfg<C8>(a, s, true);
     default: return launch_cfg<C5>(a, s, glds);
   }
 }
@@ -586,7 +595,7 @@ int mvd_gemm_pick_splitk(const MvdGemmArgs& a) {
   if (cfg < 0) return 1;
   const long tiles = (long)((a.M + kCfgs[cfg].bm - 1) / kCfgs[cfg].bm) * (a.N / kCfgs[cfg].bn);
   const int nkt = a.Ktot / 64;
-  if (cfg == 7) return (tiles >= 200 || nkt < 16) ? 1 : 2;   // one 147 KB workgroup per CU
+  if (cfg == 7 || cfg == 8) return (tiles >= 200 || nkt < 16) ? 1 : 2;   // one 115-147 KB workgroup per CU
   if (tiles >= 256 || nkt < 16) return 1;
   long s = 512 / tiles;                                       // two workgroups per CU
   if (s > nkt / 8) s = nkt / 8;
