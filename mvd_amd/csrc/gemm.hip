@@ -568,6 +568,12 @@ int mvd_launch_gemm(const MvdGemmArgs& a, hipStream_t s, int force_cfg) {
   static const int dbg = [] { const char* e = getenv("MVD_GEMM_DEBUG"); return e ? atoi(e) : 0; }();
   if (dbg) const_cast<MvdGemmArgs&>(a).dbg = dbg;
   int cfg = force_cfg;
+  // force_cfg 15 = the ring-pipelined 256x320 kernel (gemm_ring.hip); MVD_GEMM_RING=1 routes every plain 256x320 launch to it
+  static const int use_ring = [] { const char* e = getenv("MVD_GEMM_RING"); return e ? atoi(e) : 0; }();
+  if (cfg == 15) {
+    if (a.N % 320 || a.geglu || a.out_f32) { mvd_set_error("gemm: the ring kernel needs N %% 320 == 0, bf16 output, no GEGLU"); return -1; }
+    return mvd_launch_gemm_ring(a, s);
+  }
   if (cfg == 14) { glds = true; cfg = 8; }       // force_cfg 14 = the 128x320 tile (LDS-DMA only)
   else if (cfg >= 8) { glds = true; cfg -= 8; } else if (cfg >= 0 && cfg < 6) { glds = false; }
   if (cfg < 0) cfg = mvd_gemm_pick_config(a);
@@ -581,7 +587,9 @@ int mvd_launch_gemm(const MvdGemmArgs& a, hipStream_t s, int force_cfg) {
     case 6:
       if (!a.geglu || a.seg[0].mode != MVD_A_DENSE || a.splitk > 1) { mvd_set_error("gemm: tile config 6 is GEGLU-only"); return -1; }
       return launch_mode2<C6, 0, true, false>(a, s);
-    case 7: return launch_cfg<C7>(a, s, true);
+    case 7:
+      if (use_ring && !a.out_f32 && !a.dbg) return mvd_launch_gemm_ring(a, s);
+      return launch_cfg<C7>(a, s, true);
     case 8: return launch_cfg<C8>(a, s, true);
     default: return launch_cfg<C5>(a, s, glds);
   }

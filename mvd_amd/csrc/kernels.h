@@ -45,6 +45,8 @@ struct MvdGemmArgs {
 };
 
 int mvd_launch_gemm(const MvdGemmArgs& a, hipStream_t s, int force_cfg = -1);
+// ring-pipelined 256x320 kernel (gemm_ring.hip); arguments already validated by mvd_launch_gemm
+int mvd_launch_gemm_ring(const MvdGemmArgs& a, hipStream_t s);
 // sum the split-K partials and apply the GEMM epilogue (bias, row vector, alpha, residual) -> out
 int mvd_launch_splitk_reduce(const MvdGemmArgs& a, hipStream_t s);
 // split factor the engine should use for this problem (1 = none); needs splitk*M*N floats of workspace

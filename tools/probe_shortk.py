@@ -7,7 +7,7 @@ import torch
 from mvd_amd import ops
 
 CFGS = [int(c) for c in os.environ.get("PROBE_CFGS", "7,8,10,11,12").split(",")]
-TILES = {7: (256, 320), 8: (256, 160), 9: (256, 128), 10: (128, 160), 11: (128, 128), 12: (128, 64), 13: (64, 64)}
+TILES = {15: (256, 320), 7: (256, 320), 8: (256, 160), 9: (256, 128), 10: (128, 160), 11: (128, 128), 12: (128, 64), 13: (64, 64)}
 ROT = 6
 
 def rnd(*s): return (torch.randn(*s, device="cuda") * 0.5).to(torch.bfloat16)

@@ -11,6 +11,7 @@ TILES.update({k + 8: v for k, v in list(TILES.items())})
 TILES[7] = (256, 320)
 TILES[6] = (256, 320)
 TILES[14] = (128, 320)
+TILES[15] = (256, 320)   # ring-pipelined kernel
 if os.environ.get('TUNE_CFGS'):
     TILES = {int(c): TILES[int(c)] for c in os.environ['TUNE_CFGS'].split(',')}
 
@@ -45,7 +46,7 @@ for kind, name, p in shapes:
     for cfg, (bm, bn) in TILES.items():
         try:
             if kind == "lin":
-                if p["N"] % bn or (p.get("geglu") and cfg in (0, 2, 7, 8, 10, 14)): continue
+                if p["N"] % bn or (p.get("geglu") and cfg in (0, 2, 7, 8, 10, 14, 15)): continue
                 a, w = rnd(p["M"], p["K"]), rnd(p["N"], p["K"])
                 fn = lambda: ops.linear(a, w, geglu=p.get("geglu", False), force_cfg=cfg)
                 fl = 2.0 * p["M"] * p["N"] * p["K"]
