@@ -285,12 +285,241 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && NSUB == 2) ? 3 : 2) void attn_
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Software-pipelined variant (prescaled Q, 64-key tiles, 4 waves x 32 queries, two waves per SIMD / 256 registers):
+// the S^T = K.Q^T MFMAs of tile t+1 are issued UNDER the softmax of tile t (their accumulator is a second register
+// set), so the matrix pipe has work while the exp / convert stream of tile t runs, and the exp stream has MFMA shadows
+// to hide in.  K therefore runs one tile ahead of V through LDS: iteration t reads V(t) and K(t+1).
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_pipe_kernel(const MvdAttnArgs a) {
+  constexpr int NT = 64 * NW;
+  constexpr int QB = 32 * NW;
+  constexpr int KV_TILE = 64;
+  constexpr int TILE_BYTES = KV_TILE * 128;
+  constexpr int LD_IT = (KV_TILE * 8) / NT;
+  static_assert((NT / 8) % 16 == 0, "loader rows must share the swizzle pattern");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];  // K0 K1 V0 V1
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane & 31, lh = lane >> 5;
+  const int head = blockIdx.y;
+  int bz = blockIdx.z;
+  const int pi = bz / a.batch;
+  bz -= pi * a.batch;
+  const MvdAttnProblem& P = a.p[pi];
+  const int nq = P.nq, nk = P.nk;
+  const int qblk0 = blockIdx.x * QB;
+  if (qblk0 >= nq) return;
+
+  const bf16_t* qp = P.q + (size_t)bz * P.bsq + head * 64;
+  const bf16_t* kp = P.k + (size_t)bz * P.bsk + head * 64;
+  const bf16_t* vp = P.v + (size_t)bz * P.bsv + head * 64;
+  bf16_t* op = P.o + (size_t)bz * P.bso + head * 64;
+
+  const int qrow = qblk0 + wave * 32 + lq;
+  const int qrow_c = qrow < nq ? qrow : nq - 1;
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+    qf[ks] = *reinterpret_cast<const bf16x8*>(qp + (size_t)qrow_c * P.ldq + ks * 16 + lh * 8);
+
+  const int ld_kc = tid & 7, ld_row = tid >> 3;
+  const int ld_koff = k_off(ld_row, ld_kc), ld_voff = v_off(ld_row, ld_kc);
+  const int ldk = P.ldk, ldv = P.ldv;
+  const unsigned ld_ko = ((unsigned)ld_row * (unsigned)ldk + ld_kc * 8) * 2u;
+  const unsigned ld_vo = ((unsigned)ld_row * (unsigned)ldv + ld_kc * 8) * 2u;
+  const char* kp_b = reinterpret_cast<const char*>(kp);
+  const char* vp_b = reinterpret_cast<const char*>(vp);
+  u32x4 rk[LD_IT], rv[LD_IT];
+  // one operand (K or V) of key tile kb: uniform base + loop-invariant per-lane offset; ragged last tile clamps rows
+  auto load_one = [&](const char* base, int ld, unsigned lane_off, int kb, u32x4 (&r)[LD_IT]) __attribute__((always_inline)) {
+    const int k0 = kb * KV_TILE;
+    const bool full = k0 + KV_TILE <= nk;
+#pragma unroll
+    for (int i = 0; i < LD_IT; ++i) {
+      const char* b = base;
+      unsigned o;
+      if (full) {
+        b += (size_t)(k0 + i * (NT / 8)) * ld * 2;
+        o = lane_off;
+      } else {
+        int key = k0 + ld_row + i * (NT / 8);
+        key = key < nk ? key : nk - 1;
+        asm volatile("" : "+v"(key));
+        o = ((unsigned)key * (unsigned)ld + ld_kc * 8) * 2u;
+      }
+      r[i] = *reinterpret_cast<const u32x4*>(b + o);
+    }
+  };
+  auto store_k = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < LD_IT; ++i) *reinterpret_cast<u32x4*>(smem + buf * TILE_BYTES + ld_koff + i * (NT / 8) * 128) = rk[i];
+  };
+  auto store_v = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < LD_IT; ++i) *reinterpret_cast<u32x4*>(smem + (2 + buf) * TILE_BYTES + ld_voff + i * (NT / 8) * 128) = rv[i];
+  };
+
+  f32x16 o0 = {}, o1 = {}, ol = {};
+  bf16x8 ones_frag;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones_frag[j] = (lq == 0) ? (__bf16)1.0f : (__bf16)0.0f;
+  float m_run = 0.f;
+  f32x16 negm = {};
+  f32x16 sA[2], sB[2];           // score accumulators of the tile being reduced / of the tile being multiplied
+
+  const int tr_i = lane & 15;
+  const int tr_q = tr_i >> 2, tr_p = tr_i & 3;
+  const int tr_dcol = ((lane >> 4) & 1) * 16 + tr_p * 4;
+  const int tr_base0 = v_off(4 * lh + tr_q, tr_dcol >> 3) + (tr_dcol & 7) * 2;
+  const int tr_base1 = tr_base0 ^ 64;
+  int k_base[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) k_base[ks] = k_off(lq, ks * 2 + lh);
+
+  auto qk = [&](int kbuf, f32x16 (&s)[2]) __attribute__((always_inline)) {
+    const unsigned char* sk = smem + kbuf * TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + k_base[ks] + t * 32 * 128);
+        if (ks == 0) s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0], negm, 0, 0, 0);
+        else         s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t], 0, 0, 0);
+      }
+    }
+  };
+
+  const int nkb = (nk + KV_TILE - 1) / KV_TILE;
+  // ---- prologue: K(0), K(1), V(0) -> LDS ; S(0)
+  load_one(kp_b, ldk, ld_ko, 0, rk); store_k(0);
+  if (nkb > 1) { load_one(kp_b, ldk, ld_ko, 1, rk); store_k(1); }
+  load_one(vp_b, ldv, ld_vo, 0, rv); store_v(0);
+  __syncthreads();
+  qk(0, sA);
+
+  // iteration kb: s = scores of tile kb (relative to the running max they were started from), sn <- scores of tile kb+1
+  auto body = [&](int kb, int par, f32x16 (&s)[2], f32x16 (&sn)[2]) __attribute__((always_inline)) {
+    const bool have1 = kb + 1 < nkb, have2 = kb + 2 < nkb;
+    if (have2) load_one(kp_b, ldk, ld_ko, kb + 2, rk);
+    if (have1) load_one(vp_b, ldv, ld_vo, kb + 1, rv);
+    if (kb * KV_TILE + KV_TILE > nk) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kb * KV_TILE + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (key >= nk) s[t][r] = NEG_BIG;
+        }
+    }
+    float mx = s[0][0];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
+    mx = pair_max(mx);
+    if (kb == 0 || !__all(mx <= RESCALE_LOG2)) {
+      const float delta = kb == 0 ? mx : fmaxf(mx, 0.f);
+      if (kb != 0) {
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        ol[0] *= alpha;
+      }
+      m_run += delta;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) negm[r] = -m_run;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[t][r] -= delta;
+    }
+    // scores of the NEXT tile, started from the (possibly just raised) running max, interleaved at k-step granularity
+    // with the exponentials of THIS tile: two MFMAs (64 matrix-pipe cycles), then the eight v_exp_f32 of one 16-key
+    // group (64 issue cycles) in their shadow; the K fragments of the next k-step are already in flight
+    if (have1) {
+      const unsigned char* sk = smem + (par ^ 1) * TILE_BYTES;
+      bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(sk + k_base[0]);
+      bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(sk + k_base[0] + 32 * 128);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8 nf0 = kf0, nf1 = kf1;
+        if (ks < 3) {
+          nf0 = *reinterpret_cast<const bf16x8*>(sk + k_base[ks + 1]);
+          nf1 = *reinterpret_cast<const bf16x8*>(sk + k_base[ks + 1] + 32 * 128);
+        }
+        if (ks == 0) {
+          sn[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0, qf[0], negm, 0, 0, 0);
+          sn[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1, qf[0], negm, 0, 0, 0);
+        } else {
+          sn[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0, qf[ks], sn[0], 0, 0, 0);
+          sn[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1, qf[ks], sn[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[ks >> 1][8 * (ks & 1) + j] = __builtin_amdgcn_exp2f(s[ks >> 1][8 * (ks & 1) + j]);
+        __builtin_amdgcn_sched_barrier(0);
+        kf0 = nf0; kf1 = nf1;
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[t][r] = __builtin_amdgcn_exp2f(s[t][r]);
+    }
+    const unsigned char* sv = smem + (2 + par) * TILE_BYTES;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      bf16x8 pb;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pb[j] = (__bf16)s[st >> 1][8 * (st & 1) + j];
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const int offA = (dt == 0 ? tr_base0 : tr_base1) + st * 16 * 128;
+        const int offB = offA + 8 * 128;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sv + offA));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sv + offB));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const bf16x8 vf = __builtin_bit_cast(bf16x8, both);
+        if (dt == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, o0, 0, 0, 0);
+        else         o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, o1, 0, 0, 0);
+      }
+      ol = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones_frag, pb, ol, 0, 0, 0);
+    }
+    if (have2) store_k(par);          // K(kb+2) over K(kb): its S^T was formed one iteration ago
+    if (have1) store_v(par ^ 1);      // V(kb+1) over V(kb-1)
+    __syncthreads();
+  };
+  for (int kb = 0;;) {
+    body(kb, 0, sA, sB);
+    if (++kb >= nkb) break;
+    body(kb, 1, sB, sA);
+    if (++kb >= nkb) break;
+  }
+
+  const float inv = 1.0f / pair_sum(ol[0]);
+  if (qrow < nq) {
+    bf16_t* orow = op + (size_t)qrow * P.ldo;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      u32x2 w0 = {pack2bf(o0[4 * g] * inv, o0[4 * g + 1] * inv), pack2bf(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv)};
+      u32x2 w1 = {pack2bf(o1[4 * g] * inv, o1[4 * g + 1] * inv), pack2bf(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv)};
+      *reinterpret_cast<u32x2*>(orow + 8 * g + 4 * lh) = w0;
+      *reinterpret_cast<u32x2*>(orow + 32 + 8 * g + 4 * lh) = w1;
+    }
+  }
+}
+
 template <int NW, int NSUB>
 int launch_nw(const MvdAttnArgs& a, int maxq, hipStream_t s) {
   const int qb = 32 * NW;
   dim3 grid((maxq + qb - 1) / qb, a.heads, a.batch * a.nprob);
-  if (a.prescaled) hipLaunchKernelGGL((attn_kernel<NW, NSUB, true>), grid, dim3(64 * NW), 0, s, a);
-  else             hipLaunchKernelGGL((attn_kernel<NW, NSUB, false>), grid, dim3(64 * NW), 0, s, a);
+  // (the software-pipelined kernel is an experiment switch: at two waves per SIMD it measured 13 % SLOWER than the
+  //  three-wave kernel above -- inter-wave overlap beats the intra-wave pipeline hipcc schedules; MVD_ATTN_PIPE=1)
+  static const int pipe = [] { const char* e = getenv("MVD_ATTN_PIPE"); return e ? atoi(e) : 0; }();
+  if (a.prescaled && NW == 4 && NSUB == 2 && pipe) hipLaunchKernelGGL((attn_pipe_kernel<4>), grid, dim3(256), 0, s, a);
+  else if (a.prescaled) hipLaunchKernelGGL((attn_kernel<NW, NSUB, true>), grid, dim3(64 * NW), 0, s, a);
+  else                  hipLaunchKernelGGL((attn_kernel<NW, NSUB, false>), grid, dim3(64 * NW), 0, s, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { mvd_set_error("attention launch: %s", hipGetErrorString(e)); return -3; }
   return 0;

@@ -509,6 +509,7 @@ int mvd_gemm_pick_config(const MvdGemmArgs& a) {
   static const int use7 = [] { const char* e = getenv("MVD_GEMM_BIG"); return e ? atoi(e) : 1; }();
   // (128x320 tiles instead of a two-way split-K at M = 8192: measured 1 % SLOWER end to end -- the W slab is
   //  re-fetched per 128 rows and the 64x80 wave tile reads more LDS per FLOP -- so it is an opt-in switch)
+  static const int split_min_slabs = [] { const char* e = getenv("MVD_GEMM_SPLIT_MINK"); return e ? atoi(e) / 64 : 64; }();
   static const int use8 = [] { const char* e = getenv("MVD_GEMM_C8"); return e ? atoi(e) : 0; }();
   if (use7 && a.N % 320 == 0 && a.M >= 1024) {
     const long t7 = (long)((a.M + 255) / 256) * (a.N / 320);
@@ -516,7 +517,11 @@ int mvd_gemm_pick_config(const MvdGemmArgs& a) {
     // (a split of 2 at most: the fp32 partials of deeper splits cost more than the bigger tile gains)
     else if (t7 >= 200) return 7;
     else if (use8 && t7 * 2 >= 200) return 8;       // 128x320 tiles fill the chip without a split
-    else if (a.Ktot / 64 >= 16 && t7 * 2 >= 200) return 7;
+    // too few 256x320 tiles (M = 8192 at the deep levels): a two-way split-K of the big tile only pays for long K
+    // (K >= 4096: convolutions, ff2); shorter K goes to 128x160 tiles without a split -- and without the reduce pass
+    // (measured at M 8192 x N 1280: K 1280 36 us vs 41 + 15 us, K 2560 67 vs 63 + 15 us, K 5120 a tie; end to end the
+    //  rule is worth 0.2-0.5 %)
+    else if (a.Ktot / 64 >= split_min_slabs && t7 * 2 >= 200) return 7;
   }
   static const int order[] = {2, 3, 4, 5};
   int cfg = -1, first_valid = -1;
