@@ -2,6 +2,7 @@
 // conv_out, timestep + camera embeddings and the skinny fp32 linears of the camera MLPs.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include "kernels.h"
 
 static thread_local char g_err[512] = "";
@@ -184,6 +185,67 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const float* __restr
   }
 }
 
+// Vectorised form: one wave computes F output features for up to 32 batch rows, so every x element fetched serves F
+// weight rows (the x re-reads from L2 dominated the one-feature kernel); 16-byte loads of both operands.
+template <bool WBF16, int F>
+__global__ __launch_bounds__(256) void skinny_linear_vec_kernel(const float* __restrict__ x, int ldx, int batch, int k,
+                                                                 const void* __restrict__ wv, const float* __restrict__ bias,
+                                                                 int n, int act_in, float* __restrict__ y, int ldy) {
+  constexpr int BC = 32;
+  constexpr int KV = WBF16 ? 8 : 4;          // k elements per lane per iteration (16 bytes of weight)
+  const int lane = threadIdx.x & 63;
+  const int o0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * F;
+  if (o0 >= n) return;
+  for (int b0 = 0; b0 < batch; b0 += BC) {
+    float acc[BC][F];
+#pragma unroll
+    for (int j = 0; j < BC; ++j)
+#pragma unroll
+      for (int f = 0; f < F; ++f) acc[j][f] = 0.f;
+    for (int kk = lane * KV; kk < k; kk += 64 * KV) {
+      float w[F][KV];
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        const int o = o0 + f < n ? o0 + f : n - 1;
+        if (WBF16) {
+          const u32x4 r = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(wv) + (size_t)o * k + kk);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { w[f][2 * e] = bflo(r[e]); w[f][2 * e + 1] = bfhi(r[e]); }
+        } else {
+          const f32x4 r = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(wv) + (size_t)o * k + kk);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) w[f][e] = r[e];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < BC; ++j) {
+        const int jr = b0 + j < batch ? b0 + j : batch - 1;      // rows past the batch repeat the last one (never stored):
+        float xv[KV];                                            // no branch in the loop, the 32 row loads issue back to back
+#pragma unroll
+        for (int q = 0; q < KV / 4; ++q) {
+          const f32x4 x4 = *reinterpret_cast<const f32x4*>(x + (size_t)jr * ldx + kk + 4 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xv[4 * q + e] = act_in == 1 ? silu_f(x4[e]) : x4[e];
+        }
+#pragma unroll
+        for (int f = 0; f < F; ++f)
+#pragma unroll
+          for (int e = 0; e < KV; ++e) acc[j][f] = fmaf(xv[e], w[f][e], acc[j][f]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BC; ++j) {
+      if (b0 + j < batch) {
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+          const float t = wave_sum(acc[j][f]);
+          if (lane == 0 && o0 + f < n) y[(size_t)(b0 + j) * ldy + o0 + f] = t + (bias ? bias[o0 + f] : 0.f);
+        }
+      }
+    }
+  }
+}
+
 __global__ void timestep_embedding_kernel(const float* __restrict__ t, int dim, float* __restrict__ y) {
   const int b = blockIdx.x;
   const int half = dim >> 1;
@@ -341,6 +403,18 @@ int mvd_launch_f32_to_bf16(const float* x, int64_t n, bf16_t* y, hipStream_t s) 
 int mvd_launch_skinny_linear(const float* x, int ldx, int batch, int k, const void* w, int wbf16, const float* bias, int n,
                              int act_in, float* y, int ldy, hipStream_t s) {
   if (!x || !w || !y || batch <= 0 || batch > 4096 || k <= 0 || n <= 0 || ldx < k || ldy < n) { mvd_set_error("skinny_linear: bad arguments"); return -1; }
+  // vector path: 16-byte aligned rows of both operands (every MLP of the camera / time path except the 9-wide
+  // rotation input and misaligned views); two features per wave
+  const int kv = wbf16 ? 8 : 4;
+  const bool vec = (k % kv) == 0 && (ldx % 4) == 0 && (((uintptr_t)x | (uintptr_t)w) & 15) == 0;
+  static const int use_vec = [] { const char* e = getenv("MVD_SKINNY_VEC"); return e ? atoi(e) : 1; }();
+  if (vec && use_vec) {
+    constexpr int F = 2;
+    const dim3 g(nblk(n, 4 * F));
+    if (wbf16) hipLaunchKernelGGL((skinny_linear_vec_kernel<true, F>), g, dim3(256), 0, s, x, ldx, batch, k, w, bias, n, act_in, y, ldy);
+    else hipLaunchKernelGGL((skinny_linear_vec_kernel<false, F>), g, dim3(256), 0, s, x, ldx, batch, k, w, bias, n, act_in, y, ldy);
+    return check("skinny_linear");
+  }
   if (wbf16) hipLaunchKernelGGL(skinny_linear_kernel<true>, dim3(nblk(n, 4)), dim3(256), 0, s, x, ldx, batch, k, w, bias, n, act_in, y, ldy);
   else hipLaunchKernelGGL(skinny_linear_kernel<false>, dim3(nblk(n, 4)), dim3(256), 0, s, x, ldx, batch, k, w, bias, n, act_in, y, ldy);
   return check("skinny_linear");

@@ -99,19 +99,27 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
   __syncthreads();
   const int row0 = blockIdx.x * rows_per_blk;
   const int nrow = min(hw, row0 + rows_per_blk) - row0;
-  const int total = nrow * vec;
-  for (int e = threadIdx.x; e < total; e += blockDim.x) {
-    const int row = row0 + e / vec, v = e % vec, ch = v * 8;
-    const bool first = ch < c0;
-    const bf16_t* src = first ? x0 + ((size_t)b * hw + row) * c0 + ch : x1 + ((size_t)b * hw + row) * c1 + (ch - c0);
+  // element e = (row, 8-channel vector v); the (row, v) cursor advances by blockDim without a division per element,
+  // and the per-channel affine comes out of LDS as four 16-byte reads
+  int row = threadIdx.x / vec, v = threadIdx.x - row * vec;
+  const int dr = blockDim.x / vec, dv = blockDim.x - dr * vec;
+  while (row < nrow) {
+    const int ch = v * 8;
+    const size_t pix = (size_t)b * hw + row0 + row;
+    const bf16_t* src = ch < c0 ? x0 + pix * c0 + ch : x1 + pix * c1 + (ch - c0);
     float f[8];
     unpack8(*reinterpret_cast<const u32x4*>(src), f);
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(s_a + ch), a1 = *reinterpret_cast<const f32x4*>(s_a + ch + 4);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(s_b + ch), b1 = *reinterpret_cast<const f32x4*>(s_b + ch + 4);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float t = fmaf(f[j], s_a[ch + j], s_b[ch + j]);
-      f[j] = silu ? silu_f(t) : t;
+    for (int j = 0; j < 4; ++j) {
+      const float t0 = fmaf(f[j], a0[j], b0[j]), t1 = fmaf(f[j + 4], a1[j], b1[j]);
+      f[j] = silu ? silu_f(t0) : t0;
+      f[j + 4] = silu ? silu_f(t1) : t1;
     }
-    *reinterpret_cast<u32x4*>(y + ((size_t)b * hw + row) * C + ch) = pack8(f);
+    *reinterpret_cast<u32x4*>(y + pix * C + ch) = pack8(f);
+    v += dv; row += dr;
+    if (v >= vec) { v -= vec; ++row; }
   }
 }
 
