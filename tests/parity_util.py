@@ -33,11 +33,13 @@ def look_at(azim_deg: float, elev_deg: float = 20.0, radius: float = 2.0) -> tor
     return m
 
 
-def make_inputs(cfg: OU.UNetConfig, batch: int, hw: int, text_len: int, seed: int = 0, cam_dim: int = 1024):
+def make_inputs(cfg: OU.UNetConfig, batch: int, hw, text_len: int, seed: int = 0, cam_dim: int = 1024):
+    """hw: latent size, an int (square) or an (H, W) pair."""
+    h, w = (hw, hw) if isinstance(hw, int) else hw
     g = torch.Generator().manual_seed(seed)
-    sample = torch.randn(batch, cfg.in_channels, hw, hw, generator=g)
+    sample = torch.randn(batch, cfg.in_channels, h, w, generator=g)
     text = torch.randn(batch, text_len, cfg.cross_attention_dim, generator=g)
-    lat = 0.18215 * torch.randn(batch, cfg.in_channels, hw, hw, generator=g)
+    lat = 0.18215 * torch.randn(batch, cfg.in_channels, h, w, generator=g)
     src = torch.stack([look_at(0.0)] * batch)
     tgt = torch.stack([look_at([45.0, 90.0, 180.0, 270.0][b % 4]) for b in range(batch)])
     proj = OM.draw_fourier_projection(cam_dim, g)

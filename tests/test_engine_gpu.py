@@ -53,6 +53,21 @@ def test_tiny_forward_parity(tiny, cam, img, batch):
     assert max_rel(got, want) <= TOL_MAX
 
 
+@pytest.mark.parametrize("hw,batch,text_len", [((24, 40), 2, 11), ((8, 56), 1, 77), ((40, 8), 3, 5)])
+def test_tiny_nonsquare_latents(tiny, hw, batch, text_len):
+    """Non-square, non-power-of-two latents (768x1280-style images): ragged GEMM/conv tiles, ragged attention query and
+    key tiles at every level, camera + image conditioning on."""
+    from tests.parity_util import make_inputs, max_rel, rel_l2
+    cfg, params, model = tiny
+    inp = make_inputs(cfg, batch, hw, text_len, seed=7, cam_dim=96)
+    t = torch.tensor(77)
+    want = _oracle(params, cfg, inp, t, True, True)
+    got = _run(model, inp, t, True, True)
+    assert got.shape == want.shape and torch.isfinite(got).all()
+    assert rel_l2(got, want) <= TOL_L2, (rel_l2(got, want), max_rel(got, want))
+    assert max_rel(got, want) <= TOL_MAX
+
+
 def test_tiny_features_and_camera_embedding(tiny):
     """The 16 encoder feature maps (image_encoder.py hooks) and the camera embedding match the oracle."""
     from tests.parity_util import make_inputs, max_rel, rel_l2
