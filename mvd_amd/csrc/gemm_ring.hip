@@ -186,49 +186,31 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const MvdGemmArgs a) 
       }
       return full;
     }
-    f32x4 bv[RTN];
-    if (a.bias) {
-#pragma unroll
-      for (int j = 0; j < RTN; ++j) bv[j] = *reinterpret_cast<const f32x4*>(a.bias + nb + j * 16);
-    }
+    // lean on registers (the accumulators are modified in place): a spill here would put scratch reloads -- and the
+    // vmcnt(0) hipcc waits for them with -- into the main loop
     bf16_t* outp = reinterpret_cast<bf16_t*>(a.out) + nb;
 #pragma unroll
     for (int i = 0; i < RTM; ++i) {
       const int m = m0 + wm * 128 + i * 16 + fr;
       const int mc = m < a.M ? m : a.M - 1;
-      f32x4 v[RTN];
-#pragma unroll
-      for (int j = 0; j < RTN; ++j) v[j] = acc[i][j];
-      if (a.bias) {
-#pragma unroll
-        for (int j = 0; j < RTN; ++j) v[j] += bv[j];
-      }
-      if (a.rowvec) {
-        const float* rv = a.rowvec + (size_t)(mc / a.rows_per_batch) * a.ld_rowvec + nb;
-#pragma unroll
-        for (int j = 0; j < RTN; ++j) v[j] += *reinterpret_cast<const f32x4*>(rv + j * 16);
-      }
-#pragma unroll
-      for (int j = 0; j < RTN; ++j) v[j] *= alpha;
+      u32x2 r[RTN];
       if (a.res) {
         const bf16_t* rp = a.res + (size_t)mc * a.ldres + nb;
-        u32x2 r[RTN];
 #pragma unroll
         for (int j = 0; j < RTN; ++j) r[j] = *reinterpret_cast<const u32x2*>(rp + j * 16);
-#pragma unroll
-        for (int j = 0; j < RTN; ++j) { v[j][0] += bflo(r[j][0]); v[j][1] += bfhi(r[j][0]); v[j][2] += bflo(r[j][1]); v[j][3] += bfhi(r[j][1]); }
       }
+      const float* rv = a.rowvec ? a.rowvec + (size_t)(mc / a.rows_per_batch) * a.ld_rowvec + nb : nullptr;
       bf16_t* orow = outp + (size_t)m * a.ldo;
-      if (full) {
+      const bool st = full || (m < a.M && !(a.dbg & 1));
 #pragma unroll
-        for (int j = 0; j < RTN; ++j) {
-          u32x2 o = {pack2bf(v[j][0], v[j][1]), pack2bf(v[j][2], v[j][3])};
-          *reinterpret_cast<u32x2*>(orow + j * 16) = o;
-        }
-      } else if (m < a.M && !(a.dbg & 1)) {
-#pragma unroll
-        for (int j = 0; j < RTN; ++j) {
-          u32x2 o = {pack2bf(v[j][0], v[j][1]), pack2bf(v[j][2], v[j][3])};
+      for (int j = 0; j < RTN; ++j) {
+        f32x4 v = acc[i][j];
+        if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + nb + j * 16);
+        if (rv) v += *reinterpret_cast<const f32x4*>(rv + j * 16);
+        v *= alpha;
+        if (a.res) { v[0] += bflo(r[j][0]); v[1] += bfhi(r[j][0]); v[2] += bflo(r[j][1]); v[3] += bfhi(r[j][1]); }
+        if (st) {
+          u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
           *reinterpret_cast<u32x2*>(orow + j * 16) = o;
         }
       }
