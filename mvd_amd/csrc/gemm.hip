@@ -340,22 +340,30 @@ __global__ __launch_bounds__(C::NT, C::MIN_WAVES) void gemm_kernel(const MvdGemm
             __builtin_amdgcn_sched_barrier(0);
           }
 #else
-          // software pipeline: the next pair of A fragments is read while the MFMAs of the current pair run
-          bf16x8 a0 = *reinterpret_cast<const bf16x8*>(sa + swz_off(wm * C::WTM + fr, s2 * 4 + fq));
-          bf16x8 a1 = *reinterpret_cast<const bf16x8*>(sa + swz_off(wm * C::WTM + 16 + fr, s2 * 4 + fq));
+          // software pipeline over BOTH 32-wide halves of the slab (8 steps of two row tiles): the next pair of A
+          // fragments is read while the MFMAs of the current pair run, and during the last pair of the first half each
+          // W fragment is replaced in place by its second-half successor as soon as its last MFMA has issued -- the
+          // second half starts without waiting for LDS
+          if (s2 == 1) continue;
+          auto a_at = [&](int q) __attribute__((always_inline)) -> bf16x8 {   // q = half * TM + row tile
+            return *reinterpret_cast<const bf16x8*>(sa + swz_off(wm * C::WTM + (q % C::TM) * 16 + fr, (q / C::TM) * 4 + fq));
+          };
+          bf16x8 a0 = a_at(0), a1 = a_at(1);
 #pragma unroll
-          for (int i = 0; i < C::TM; i += 2) {
+          for (int q = 0; q < 2 * C::TM; q += 2) {
+            const int i = q % C::TM;
             bf16x8 n0 = a0, n1 = a1;
-            if (i + 2 < C::TM) {
-              n0 = *reinterpret_cast<const bf16x8*>(sa + swz_off(wm * C::WTM + (i + 2) * 16 + fr, s2 * 4 + fq));
-              n1 = *reinterpret_cast<const bf16x8*>(sa + swz_off(wm * C::WTM + (i + 3) * 16 + fr, s2 * 4 + fq));
-            }
+            if (q + 2 < 2 * C::TM) { n0 = a_at(q + 2); n1 = a_at(q + 3); }
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int j = 0; j < C::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], a0, acc[i][j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < C::TN; ++j) acc[i + 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], a1, acc[i + 1][j], 0, 0, 0);
+            for (int j = 0; j < C::TN; ++j) {
+              acc[i + 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], a1, acc[i + 1][j], 0, 0, 0);
+              if (q == C::TM - 2)   // last pair of the first half
+                wf[j] = *reinterpret_cast<const bf16x8*>(sb + swz_off(wn * C::WTN + j * 16 + fr, 4 + fq));
+            }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             a0 = n0; a1 = n1;
