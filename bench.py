@@ -109,7 +109,12 @@ def main():
     args = ap.parse_args()
 
     from mvd_amd import distributed as D
-    rank, world, local = D.init_from_env("nccl")
+    # MVD_BENCH_REHEARSAL=1: every rank on cuda:0 with the gloo backend -- a one-GPU rehearsal of the N > 1 control flow
+    # (weight broadcast, barriers, max over ranks); the numbers of such a run mean nothing
+    rehearsal = os.environ.get("MVD_BENCH_REHEARSAL") == "1"
+    rank, world, local = D.init_from_env("gloo" if rehearsal else "nccl")
+    if rehearsal:
+        local = 0
     if world != args.gpus:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
