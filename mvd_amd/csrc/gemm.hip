@@ -240,24 +240,35 @@ __global__ __launch_bounds__(C::NT, C::MIN_WAVES) void gemm_kernel(const MvdGemm
       }
       return;
     }
+    // Residual rows are fetched for RG row tiles at a time: hipcc waits vmcnt(0) for them (an LDS-DMA is in flight),
+    // which also drains the stores issued so far, so every load batch costs a full memory round trip -- 2 (dense) or
+    // 4 (conv: fewer spare registers) per tile instead of one per row tile.
+    constexpr int RG = (C::TM % 4 == 0 && AMODE == 0) ? 4 : (C::TM % 2 == 0 ? 2 : 1);
 #pragma unroll
-    for (int i = 0; i < C::TM; ++i) {
+    for (int i0 = 0; i0 < C::TM; i0 += RG) {
+      u32x2 res_r[RG][C::TN > 5 ? 1 : C::TN];
+      if (!(C::TN > 5 || a.geglu) && a.res) {
+#pragma unroll
+        for (int g = 0; g < RG; ++g) {
+          int mr = m0 + wm * C::WTM + (i0 + g) * 16 + fr;
+          mr = mr < a.M ? mr : a.M - 1;
+          const bf16_t* rp = a.res + (size_t)mr * a.ldres + nb;
+#pragma unroll
+          for (int j = 0; j < (C::TN > 5 ? 1 : C::TN); ++j) res_r[g][j] = *reinterpret_cast<const u32x2*>(rp + j * 16);
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < RG; ++g) {
+      const int i = i0 + g;
       const int m = m0 + wm * C::WTM + i * 16 + fr;
       const bool live = m < a.M;
-      const int mc = live ? m : a.M - 1;
       if (!(C::TN > 5 || a.geglu)) {       // configs with TN > 5 exist for GEGLU only
-        u32x2 res_r[C::TN];
-        if (a.res) {
-          const bf16_t* rp = a.res + (size_t)mc * a.ldres + nb;
 #pragma unroll
-          for (int j = 0; j < C::TN; ++j) res_r[j] = *reinterpret_cast<const u32x2*>(rp + j * 16);
-        }
-#pragma unroll
-        for (int j = 0; j < C::TN; ++j) {
+        for (int j = 0; j < (C::TN > 5 ? 1 : C::TN); ++j) {
           const int n = nb + j * 16;
           f32x4 v = acc[i][j] * alpha;
           if (a.res) {
-            v[0] += bflo(res_r[j][0]); v[1] += bfhi(res_r[j][0]); v[2] += bflo(res_r[j][1]); v[3] += bfhi(res_r[j][1]);
+            v[0] += bflo(res_r[g][j][0]); v[1] += bfhi(res_r[g][j][0]); v[2] += bflo(res_r[g][j][1]); v[3] += bfhi(res_r[g][j][1]);
           }
           if (!live || (a.dbg & 1)) continue;
           if (a.out_f32) {
@@ -279,6 +290,7 @@ __global__ __launch_bounds__(C::NT, C::MIN_WAVES) void gemm_kernel(const MvdGemm
             *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.ldo + no) = o;
           }
         }
+      }
       }
     }
   };
