@@ -212,7 +212,16 @@ __global__ __launch_bounds__(C::NT, C::MIN_WAVES) void gemm_kernel(const MvdGemm
         for (int i = 0; i < C::TM; ++i) acc[i][j] = bv;
       }
     }
-    if (C::TN <= 5 && a.rowvec) {          // (GEGLU-only configs never carry a row vector)
+    if (C::TN <= 5 && a.rowvec && a.rows_per_batch % C::BM == 0) {
+      // the whole tile lies in one batch element (every level but the 8x8 one): one vector for all rows, one load batch
+      const float* rv = a.rowvec + (size_t)(m0 / a.rows_per_batch) * a.ld_rowvec + nb;
+#pragma unroll
+      for (int j = 0; j < C::TN; ++j) {
+        const f32x4 r = *reinterpret_cast<const f32x4*>(rv + j * 16);
+#pragma unroll
+        for (int i = 0; i < C::TM; ++i) acc[i][j] += r;
+      }
+    } else if (C::TN <= 5 && a.rowvec) {   // (GEGLU-only configs never carry a row vector)
 #pragma unroll
       for (int i = 0; i < C::TM; ++i) {
         int m = m0 + wm * C::WTM + i * 16 + fr;
