@@ -1,6 +1,7 @@
 // Normalisation kernels (HBM-bound, 16-byte vectorised): GroupNorm(+SiLU) over NHWC with an
 // optional two-source channel concat, LayerNorm, and the MVD reference-feature
 // normalisation (per pixel over batch x channel, attention.py:95-103 of the reference).
+#include <stdlib.h>
 #include "kernels.h"
 
 namespace {
@@ -268,7 +269,8 @@ int mvd_launch_groupnorm(const bf16_t* x0, const bf16_t* x1, int c0, int c1, int
   const int threads = ((vec * R + 63) / 64) * 64;
   // enough workgroups to cover the chip even at batch 1: >= ~512 blocks when the map is large enough,
   // at least 8 rows per chunk
-  int nchunk = hw / 64;
+  static const int rows_target = [] { const char* e = getenv("MVD_GN_ROWS"); return e ? atoi(e) : 128; }();
+  int nchunk = hw / rows_target;
   if ((long)nchunk * batch < 512) nchunk = (512 + batch - 1) / batch;
   if (nchunk > hw / 8) nchunk = hw / 8;
   nchunk = nchunk < 1 ? 1 : (nchunk > MVD_GN_MAXCHUNK ? MVD_GN_MAXCHUNK : nchunk);
