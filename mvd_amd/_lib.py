@@ -95,6 +95,10 @@ def lib() -> C.CDLL:
             raise MvdError(
                 f"{LIB_PATH} not found: build the HIP extension first "
                 "(python -c 'import __graft_entry__ as g; g.build()' or python mvd_amd/_build.py)")
+        # torch first: it ships its own libamdhip64 and must be the HIP runtime of the process -- if this library (linked
+        # against /opt/rocm's copy) were loaded before torch, two runtimes would coexist and every launch on torch's
+        # device pointers would fail ("no ROCm-capable device")
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)  # AttributeError if a declared symbol is not exported
