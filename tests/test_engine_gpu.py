@@ -114,6 +114,39 @@ def test_tiny_reference_cache_is_exact(tiny):
     assert torch.equal(a, b)
 
 
+def test_tiny_streams_shapes_and_two_engines(tiny):
+    """Host-side robustness of the boundary: (i) a forward issued on a non-default stream equals the default-stream one,
+    (ii) batch / latent size may change from call to call (workspace and reference cache are re-sized), (iii) a second
+    engine alive in the same process does not disturb the first."""
+    from tests.parity_util import build_pair, make_inputs
+    cfg, params, model = tiny
+
+    def run(m, inp, t=250):
+        m.fourier_projection = inp["proj"].cuda()
+        with torch.no_grad():
+            return m(inp["sample"].cuda(), torch.tensor(t), inp["text"].cuda(), source_camera=inp["src"].cuda(),
+                     target_camera=inp["tgt"].cuda(), source_image_latents=inp["lat"].cuda()).sample
+
+    a_in = make_inputs(cfg, 2, 16, 7, seed=11, cam_dim=96)
+    b_in = make_inputs(cfg, 5, (8, 24), 9, seed=12, cam_dim=96)
+    a0 = run(model, a_in).clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        a1 = run(model, a_in).clone()
+    side.synchronize()
+    assert torch.equal(a0, a1)                       # (i)
+    b0 = run(model, b_in).clone()                    # (ii) bigger batch, other latent size, other text length
+    a2 = run(model, a_in).clone()                    #      ... and back
+    assert torch.isfinite(b0).all() and b0.shape == (5, cfg.in_channels, 8, 24)
+    assert torch.equal(a0, a2)
+    _, _, other = build_pair("tiny", 1, 96, 48)      # (iii) second engine, different weights
+    o = run(other, a_in)
+    assert not torch.equal(o, a0)
+    assert torch.equal(run(model, a_in), a0)
+    del other
+
+
 def test_sd21_full_size_parity():
     """Full SD-2.1 shapes (865.9 M + 99.2 M + 19.1 M parameters), B=1, 64x64 latent, 77 text tokens."""
     if not torch.cuda.is_available():
