@@ -392,20 +392,38 @@ __global__ __launch_bounds__(C::NT, C::MIN_WAVES) void gemm_kernel(const MvdGemm
 #endif
           continue;
         } else if constexpr (C::TN > 5) {
-          // wide wave tile (160 columns, used for GEGLU where value/gate tiles must pair up): stream the W fragments
+          // wide wave tile (160 columns, used for GEGLU where value/gate tiles must pair up): the W fragments are
+          // streamed in pairs through ONE software pipeline over both 32-wide halves of the slab (the next pair is read
+          // while the 2 x TM MFMAs of the current pair run; the A fragments of the second half replace those of the
+          // first in place during its last pair)
+          if (s2 == 1) continue;
+          constexpr int NP = C::TN / 2;                        // W pairs per half
+          auto w_at = [&](int q, int which) __attribute__((always_inline)) -> bf16x8 {   // q = half * NP + pair
+            return *reinterpret_cast<const bf16x8*>(sb + swz_off(wn * C::WTN + (2 * (q % NP) + which) * 16 + fr, (q / NP) * 4 + fq));
+          };
           bf16x8 af[C::TM];
 #pragma unroll
           for (int i = 0; i < C::TM; ++i)
-            af[i] = *reinterpret_cast<const bf16x8*>(sa + swz_off(wm * C::WTM + i * 16 + fr, s2 * 4 + fq));
+            af[i] = *reinterpret_cast<const bf16x8*>(sa + swz_off(wm * C::WTM + i * 16 + fr, fq));
+          bf16x8 w0 = w_at(0, 0), w1 = w_at(0, 1);
 #pragma unroll
-          for (int j = 0; j < C::TN; j += 2) {
-            const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(sb + swz_off(wn * C::WTN + j * 16 + fr, s2 * 4 + fq));
-            const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(sb + swz_off(wn * C::WTN + (j + 1) * 16 + fr, s2 * 4 + fq));
+          for (int q = 0; q < 2 * NP; ++q) {
+            const int j = 2 * (q % NP);
+            bf16x8 n0 = w0, n1 = w1;
+            if (q + 1 < 2 * NP) { n0 = w_at(q + 1, 0); n1 = w_at(q + 1, 1); }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < C::TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, af[i], acc[i][j], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < C::TM; ++i) acc[i][j + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, af[i], acc[i][j + 1], 0, 0, 0);
+            for (int i = 0; i < C::TM; ++i) {
+              acc[i][j + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, af[i], acc[i][j + 1], 0, 0, 0);
+              if (q == NP - 1)   // last pair of the first half: this A fragment is done, fetch its second-half successor
+                af[i] = *reinterpret_cast<const bf16x8*>(sa + swz_off(wm * C::WTM + i * 16 + fr, 4 + fq));
+            }
+            __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
+            w0 = n0; w1 = n1;
           }
           continue;
         }
