@@ -280,7 +280,8 @@ int mvd_launch_groupnorm(const bf16_t* x0, const bf16_t* x1, int c0, int c1, int
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, batch), dim3(threads), sh1, s, x0, x1, c0, c1, hw, groups, rpc, R, ws);
   if (int r = check_launch("gn_stats")) return r;
   // apply: ~16K elements per block, fewer when that would leave CUs idle (small batch)
-  long per_blk = 16384;
+  static const long per_blk_env = [] { const char* e = getenv("MVD_GN_APPLY_ELEMS"); return e ? atol(e) : 65536L; }();
+  long per_blk = per_blk_env;
   const long total_el = (long)batch * hw * C;
   if (total_el / per_blk < 1024) per_blk = total_el / 1024 < 2048 ? 2048 : total_el / 1024;
   int rows_per_blk = (int)((per_blk + C - 1) / C);
