@@ -58,7 +58,10 @@ def fill_synthetic_weights(model, seed: int = 0):
 
 
 def make_batch(pairs: int, rank: int, device):
-    from tests.parity_util import look_at
+    """8 objects x 4 target views per 32 pairs.  As pipeline.py:111-116 does, each object's source IMAGE is repeated per
+    view (so text and source latents repeat 4x here); the reference then draws ``latent_dist.sample()`` per row, which a
+    deterministic synthetic batch does not imitate -- the engine makes no use of the repetition either way."""
+    from mvd_amd.utils import look_at
     g = torch.Generator().manual_seed(1000 + rank)
     objs = max(1, pairs // 4)
     views = pairs // objs
@@ -71,9 +74,12 @@ def make_batch(pairs: int, rank: int, device):
     return {k: v.to(device).contiguous() for k, v in dict(sample=sample, text=text, lat=lat, src=src, tgt=tgt, t=t).items()}
 
 
-def cpu_baseline(timed_runs: int = 1):
-    """The oracle (CPU fp32 restatement, oracle/mvd.py) timed on this box's host cores: configs[2]
-    (B=1, adapter + camera on, cold forward).  ~10 s per forward on 16 cores."""
+def cpu_baseline(timed_runs: int = 3, warmup_runs: int = 1):
+    """The oracle (CPU fp32 restatement, oracle/mvd.py) timed on this box's host cores: configs[2] (B=1, adapter + camera
+    on, cold forward; ~13 s per forward on the GPU box's 128 usable threads).  BASELINE.md section 3 protocol: 1 warm-up
+    forward, then ``timed_runs`` timed ones, MEDIAN reported (~55 s of CPU work in all).  The only place bench.py
+    touches ``oracle/`` (and tests/parity_util, which imports it)."""
+    import statistics
     from oracle import mvd as OM
     from oracle import sd21_unet as OU
     from tests.parity_util import make_inputs
@@ -85,15 +91,53 @@ def cpu_baseline(timed_runs: int = 1):
     inp = make_inputs(cfg, 1, 64, 77, 0, 1024)
     times = []
     with torch.no_grad():
-        for i in range(timed_runs):
+        for i in range(warmup_runs + timed_runs):
             t0 = time.perf_counter()
             OM.multiview_unet_forward(params, cfg, inp["sample"], torch.tensor(500), inp["text"], inp["src"], inp["tgt"],
                                       inp["lat"], fourier_proj=inp["proj"])
-            times.append(time.perf_counter() - t0)
-    best = min(times)
-    return {"value": 1.0 / best, "unit": "forward-passes/s", "cores": cores, "kind": "port",
+            if i >= warmup_runs:
+                times.append(time.perf_counter() - t0)
+    med = statistics.median(times)
+    return {"value": 1.0 / med, "unit": "forward-passes/s", "cores": cores, "kind": "port",
             "sample": f"oracle/mvd.py, configs[2] (B=1, 64x64 latent, adapter+camera on, cold forward = {(F_ADAPTER_MAIN + F_ENCODER) / 1e9:.0f} GFLOP), "
-                      f"{timed_runs} timed forward(s), torch fp32 on {cores} host threads (os.cpu_count()={os.cpu_count()}), {best:.2f} s/forward"}
+                      f"{warmup_runs} warm-up + {timed_runs} timed forwards (median; min {min(times):.2f} s, max {max(times):.2f} s), "
+                      f"torch fp32 on {cores} host threads (os.cpu_count()={os.cpu_count()}), {med:.2f} s/forward"}
+
+
+def kernel_source_sha() -> str:
+    """Hash of the HIP sources + headers the library is built from: PMC summaries under profiles/ are stamped with it,
+    and ``roofline.traffic`` is only quoted from a summary taken on THIS source state."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "mvd_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def output_check(model, batch, kw, step):
+    """Cheap screens on the numbers the timed kernels produce (the parity proper is tests/test_cfg4_shapes_gpu.py):
+    (a) two forwards of the same batch with the Fourier projection pinned are BIT-identical (race / uninitialised-read
+    screen on the persistent multi-tile kernels); (b) with image conditioning off (no batch coupling, Q2) rows 0-1 of
+    the full-batch forward equal a batch-2 forward of the same rows -- computed by different tile configurations and
+    grids -- to bf16 accumulation-order noise."""
+    keep = model.fourier_projection
+    model.fourier_projection = model.camera_encoder.draw_projection(batch["sample"].device) if model.camera_encoder is not None else None
+    a, b = step().clone(), step().clone()
+    res = {"deterministic": bool(torch.equal(a, b))}
+    assert res["deterministic"], "two forwards of the same inputs differ"
+    cam = {k: v for k, v in kw.items() if k != "source_image_latents"}
+    if batch["sample"].shape[0] >= 4:
+        with torch.no_grad():
+            full = model(batch["sample"], batch["t"], batch["text"], **cam).sample[:2]
+            small = model(batch["sample"][:2], batch["t"][:2], batch["text"][:2], **{k: v[:2] for k, v in cam.items()}).sample
+        rel = ((full - small).norm() / small.norm()).item()
+        res["full_batch_vs_batch2_rel_l2"] = round(rel, 6)
+        assert rel <= 1.5e-2, f"full-batch rows differ from their batch-2 recomputation: rel-L2 {rel}"
+    model.fourier_projection = keep
+    return res
 
 
 def main():
@@ -106,12 +150,15 @@ def main():
     ap.add_argument("--cached", action="store_true", help="reuse the step-invariant reference K/V (Q5) instead of re-running the encoder")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="skip the determinism / cross-path output screens")
+    ap.add_argument("--shapes-out", default="", help="write the per-shape kernel table of the profiled steps to this file")
     args = ap.parse_args()
 
     from mvd_amd import distributed as D
     # MVD_BENCH_REHEARSAL=1: every rank on cuda:0 with the gloo backend -- a one-GPU rehearsal of the N > 1 control flow
     # (weight broadcast, barriers, max over ranks); the numbers of such a run mean nothing
     rehearsal = os.environ.get("MVD_BENCH_REHEARSAL") == "1"
+    # (init_from_env selects cuda:LOCAL_RANK before the RCCL process group is created)
     rank, world, local = D.init_from_env("gloo" if rehearsal else "nccl")
     if rehearsal:
         local = 0
@@ -161,6 +208,7 @@ def main():
         out = step()
     torch.cuda.synchronize()
     assert torch.isfinite(out).all(), "non-finite UNet output"
+    check = None if args.no_check else output_check(model, batch, kw, step)
     D.barrier()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -189,6 +237,10 @@ def main():
         for _ in range(nprof):
             step()
         torch.cuda.synchronize()
+        if args.shapes_out and rank == 0:
+            with open(args.shapes_out, "w") as f:
+                f.write(f"# {args.workload} {'cached' if args.cached else 'cold'} pairs={pairs}, {nprof} profiled steps, kernel_src_sha={kernel_source_sha()}\n")
+                f.write(eng.profile_shapes())
         classes = eng.profile_summary()
         eng.set_profiling(False)
         tot_ms = sum(c["ms"] for c in classes.values())
@@ -200,15 +252,18 @@ def main():
             # HBM bytes per launch of that kernel class from the committed rocprofv3 --pmc passes of this command
             # (FETCH_SIZE x2 + WRITE_SIZE, gfx950 corrections; tools/pmc_summary.py) -- PMC cannot run inside bench.py
             traffic = None
+            traffic_file = os.path.join("profiles", "r02_pmc_hbm_traffic.json")
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
-                if args.workload == "cfg4" and not args.cached and dom in pmc:
+                pmc = json.load(open(os.path.join(ROOT, traffic_file)))
+                # only a summary taken on THIS kernel source state and THIS workload is quoted (else null)
+                if (pmc.get("_meta", {}).get("kernel_src_sha") == kernel_source_sha() and args.workload == "cfg4"
+                        and not args.cached and dom in pmc):
                     traffic = round(pmc[dom]["hbm_bytes_per_launch"])
             except (OSError, ValueError):
                 pass
             roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA / 1e12,
                         "unit": "TFLOP/s", "frac": round(ach * 1e12 / PEAK_BF16_MFMA, 4), "traffic": traffic,
-                        "traffic_source": "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" if traffic else None,
+                        "traffic_source": f"{traffic_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same kernel sources)" if traffic else None,
                         "flops_per_launch": round(c["flops"] / c["launches"]),
                         "avg_launch_us": round(c["ms"] * 1e3 / c["launches"], 2), "launches_per_step": c["launches"] // nprof,
                         "share_of_step_time": round(c["ms"] / tot_ms, 3),
@@ -222,7 +277,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(1)
+        cpu = cpu_baseline(3, 1)
 
     if rank == 0:
         line = {
@@ -234,7 +289,7 @@ def main():
                        "latent": "64x64x4", "text_tokens": 77, "forward": forward_kind,
                        "gflop_per_pair": round(flops_pair / 1e9, 2), "parallelism": f"dp{world} (pairs sharded by object)",
                        "weights": "synthetic seeded, SD2.1 shapes (865.9M UNet x2 + 99.2M adapter + 19.1M camera)"},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "output_check": check, "kernel_src_sha": kernel_source_sha(),
             "gpu_ms_per_step_events": round(gpu_ms / args.steps, 3),
             "weight_bytes_bf16_packed": weight_bytes,
             "weight_broadcast": {"bytes": bc["bytes"], "seconds": round(bc["seconds"], 4), "buckets": bc["buckets"]},

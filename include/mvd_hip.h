@@ -86,6 +86,9 @@ typedef struct {
   const float* source_camera;/* [batch][cam_rows][4] or NULL                                             */
   const float* target_camera;
   int cam_rows;              /* 3 or 4 (Q8)                                                              */
+  int cam_batch;             /* rows of the camera tensors: 0 or `batch`, or a divisor of `batch` (1 = torch's
+                                (1,C,1,1) broadcast; under CFG the 2B latents share the B cameras: row b uses
+                                camera b % cam_batch) -- pipeline.py:141-152                                   */
   const float* fourier_proj; /* [cam_output_dim][6*((cam_output_dim/2)/3)] the per-call random matrix Q1 */
   const float* source_latents;/* [ref_batch][in_channels][H][W] or NULL                                  */
   const float* encoder_text; /* [ref_batch][text_len][xdim]: text rows chosen per mvd_unet.py:278-285     */
@@ -96,10 +99,18 @@ typedef struct {
 
 int mvd_unet_forward(mvd_engine_t* e, const mvd_forward_args_t* args, void* stream);
 
+/* N4 (training.py:60-65, config/train_config.yaml:43): when the image encoder's UNet weights are identical to the
+ * base UNet's (frozen base), the encoder pass can read weight set 0 and set 1 need not be registered at all. */
+int mvd_engine_share_encoder_weights(mvd_engine_t* e, int enable);
+
 /* Per-kernel-class timing with HIP events on the launch stream (measurement only; off by default).
  * classes: 0..7 GEMM/conv tile config, 12 the 128x320 tile, 8..11 attention (1,2,4,8 waves), 16 groupnorm, 17 layernorm. */
 int mvd_engine_set_profiling(mvd_engine_t* e, int enable);
 int mvd_engine_profile_summary(mvd_engine_t* e, int cap, int* cls, int* launches, double* ms, double* flops, double* bytes);
+/* Per-shape text table ("cls M N K tag launches ms tflops" per line) of the launches recorded since profiling was
+ * enabled, written to a HOST buffer; call before mvd_engine_profile_summary (which resets the records).
+ * Returns the number of bytes written (<0 on error). */
+int mvd_engine_profile_shapes(mvd_engine_t* e, char* buf_host, int cap);
 
 /* Number / shape / copy-out (NCHW fp32) of the encoder feature maps (image_encoder.py:36-84). */
 int mvd_engine_num_features(mvd_engine_t* e);
@@ -144,6 +155,13 @@ int mvd_op_nchw_to_nhwc(const float* x, int batch, int c, int hw, const float* s
 int mvd_op_nhwc_to_nchw(const void* x, int batch, int hw, int c, float* y, void* stream);
 int mvd_op_f32_to_bf16(const float* x, int64_t n, void* y, void* stream);
 int mvd_gemm_num_configs(void);
+/* What the calling thread's last GEMM/conv launch did: out[5] = {tile config, split-K, work items, workgroups, workgroups
+ * per CU}; last attention launch: out[2] = {waves per workgroup, workgroups}.  Parity tests assert with these that the
+ * persistent multi-tile path (work items > workgroups) is what ran at the benchmarked shapes. */
+int mvd_debug_last_gemm_plan(int* out);
+int mvd_debug_last_attention_plan(int* out);
+/* The split-K factor the engine's schedule picks for a GEMM/conv of this size (1 = none). */
+int mvd_debug_pick_splitk(int m, int n, int k, int geglu);
 
 /* ---- denoising-loop helpers either side of the UNet, fp32 latents ------ */
 /* DDPM ancestral step, coefficients from mvd_amd/scheduler.py (diffusers DDPMScheduler.step algebra):

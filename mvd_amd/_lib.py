@@ -33,7 +33,7 @@ class mvd_forward_args_t(C.Structure):
     _fields_ = [
         ("batch", C.c_int), ("height", C.c_int), ("width", C.c_int), ("text_len", C.c_int),
         ("sample", C.c_void_p), ("timesteps", C.c_void_p), ("text", C.c_void_p),
-        ("source_camera", C.c_void_p), ("target_camera", C.c_void_p), ("cam_rows", C.c_int),
+        ("source_camera", C.c_void_p), ("target_camera", C.c_void_p), ("cam_rows", C.c_int), ("cam_batch", C.c_int),
         ("fourier_proj", C.c_void_p), ("source_latents", C.c_void_p), ("encoder_text", C.c_void_p),
         ("ref_batch", C.c_int), ("flags", C.c_int), ("out", C.c_void_p),
     ]
@@ -52,6 +52,8 @@ _SIGS = {
     "mvd_engine_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "mvd_engine_profile_summary": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                              C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "mvd_engine_profile_shapes": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "mvd_engine_share_encoder_weights": (C.c_int, [C.c_void_p, C.c_int]),
     "mvd_engine_num_features": (C.c_int, [C.c_void_p]),
     "mvd_engine_feature_shape": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mvd_engine_get_feature": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
@@ -77,6 +79,9 @@ _SIGS = {
     "mvd_op_nhwc_to_nchw": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mvd_op_f32_to_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "mvd_gemm_num_configs": (C.c_int, []),
+    "mvd_debug_last_gemm_plan": (C.c_int, [C.POINTER(C.c_int)]),
+    "mvd_debug_last_attention_plan": (C.c_int, [C.POINTER(C.c_int)]),
+    "mvd_debug_pick_splitk": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "mvd_op_ddpm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float,
                                    C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
     "mvd_op_cfg_combine": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -6,7 +6,8 @@
 Inside ``MultiViewUNet.forward`` the adapter branch is fused into the engine's schedule
 (fused q/k/v GEMMs, one attention launch for the block's own attention + the cross-view
 attention, K-concatenated out-projection).  ``__call__`` below is the stand-alone protocol
-entry point; it runs the same HIP kernels through ``mvd_amd.ops`` -- no torch arithmetic.
+entry point: the wrapped ``original_processor`` is ``AttnProcessor2_0HIP`` (the block's own attention) and the
+reference branch runs the same HIP kernels through ``mvd_amd.ops`` -- no torch arithmetic, no CPU fallback.
 """
 from __future__ import annotations
 
@@ -20,6 +21,44 @@ from . import ops
 
 def _bf16c(t: torch.Tensor) -> torch.Tensor:
     return t.detach().to(device="cuda", dtype=torch.bfloat16).contiguous()
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(device="cuda", dtype=torch.float32).contiguous()
+
+
+class AttnProcessor2_0HIP:
+    """Stand-alone equivalent of diffusers-0.32.2 ``AttnProcessor2_0`` -- the ``original_processor`` the adapter wraps
+    (/root/reference/src/models/attention.py:62-70) -- on the HIP kernels: ``to_q/to_k/to_v`` GEMMs, softmax(q.k^T/8).v per
+    64-wide head, ``to_out[0]`` (+bias); dropout p=0, no mask, no group norm, residual_connection False,
+    rescale_output_factor 1 (the SD-2.1 attention config).  Inside ``MultiViewUNet.forward`` the same arithmetic is
+    fused into the engine's schedule; this entry point serves callers that drive a processor by hand."""
+
+    def __call__(self, attn: Any, hidden_states: torch.Tensor, encoder_hidden_states: Optional[torch.Tensor] = None,
+                 attention_mask: Optional[torch.Tensor] = None, temb: Optional[torch.Tensor] = None, *args, **kwargs):
+        if attention_mask is not None:
+            raise ValueError("AttnProcessor2_0HIP: attention masks are not supported (the MVD path never passes one)")
+        inner = attn.to_q.out_features
+        if inner != attn.heads * 64:
+            raise ValueError("the HIP attention kernel supports dim_head == 64 only")
+        out_dtype, out_device = hidden_states.dtype, hidden_states.device
+        input_ndim = hidden_states.ndim
+        if input_ndim == 4:
+            b, c, hh, ww = hidden_states.shape
+            hidden_states = hidden_states.view(b, c, hh * ww).transpose(1, 2)
+        B, N, C = hidden_states.shape
+        ctx = hidden_states if encoder_hidden_states is None else encoder_hidden_states
+        L = ctx.shape[1]
+        h = _bf16c(hidden_states).reshape(B * N, C)
+        x = _bf16c(ctx).reshape(B * L, ctx.shape[2])
+        q = ops.linear(h, _bf16c(attn.to_q.weight)).view(B, N, inner)
+        wkv = torch.cat([_bf16c(attn.to_k.weight), _bf16c(attn.to_v.weight)], 0).contiguous()
+        kv = ops.linear(x, wkv).view(B, L, 2 * inner)
+        o = ops.attention(q, kv[:, :, :inner], kv[:, :, inner:], attn.heads)
+        out = ops.linear(o.reshape(B * N, inner), _bf16c(attn.to_out[0].weight), _f32c(attn.to_out[0].bias)).view(B, N, C)
+        if input_ndim == 4:
+            out = out.transpose(-1, -2).reshape(b, c, hh, ww)
+        return out.to(device=out_device, dtype=out_dtype)
 
 
 class ImageCrossAttentionProcessor(nn.Module):
@@ -54,14 +93,16 @@ class ImageCrossAttentionProcessor(nn.Module):
         nk = Br * H * W // Bh                                               # Q4: view(batch_of_hidden, -1, heads, d)
         kv = kv.view(Bh, nk, 2 * self.inner_dim)
         o = ops.attention(q, kv[:, :, : self.inner_dim], kv[:, :, self.inner_dim:], self.heads)
-        out = ops.linear(o.reshape(Bh * N, self.inner_dim), _bf16c(self.to_out_ref[0].weight),
-                         self.to_out_ref[0].bias.detach().to(device="cuda", dtype=torch.float32).contiguous())
+        out = ops.linear(o.reshape(Bh * N, self.inner_dim), _bf16c(self.to_out_ref[0].weight), _f32c(self.to_out_ref[0].bias))
         return out.view(Bh, N, Cq)
 
     def __call__(self, attn: Any, hidden_states: torch.Tensor, encoder_hidden_states: Optional[torch.Tensor] = None,
                  attention_mask: Optional[torch.Tensor] = None, temb: Optional[torch.Tensor] = None,
                  ref_hidden_states: Optional[Dict[str, torch.Tensor]] = None, *args, **kwargs) -> torch.Tensor:
         kwargs.pop("debug_log_file_path", None)
+        if self.original_processor is None:
+            raise RuntimeError(f"ImageCrossAttentionProcessor '{self.name}' has no original_processor "
+                               "(construct it with get_attention_processor_for_module)")
         original_output = self.original_processor(attn, hidden_states, encoder_hidden_states, attention_mask,
                                                   temb=temb, *args, **kwargs)
         if ref_hidden_states is None or self.name not in ref_hidden_states:

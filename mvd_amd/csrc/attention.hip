@@ -510,13 +510,16 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_pipe_kernel(const MvdAttnArgs
   }
 }
 
+thread_local int g_last_attn[2] = {0, 0};
+
 template <int NW, int NSUB>
 int launch_nw(const MvdAttnArgs& a, int maxq, hipStream_t s) {
   const int qb = 32 * NW;
   dim3 grid((maxq + qb - 1) / qb, a.heads, a.batch * a.nprob);
   // (the software-pipelined kernel is an experiment switch: at two waves per SIMD it measured 13 % SLOWER than the
   //  three-wave kernel above -- inter-wave overlap beats the intra-wave pipeline hipcc schedules; MVD_ATTN_PIPE=1)
-  static const int pipe = [] { const char* e = getenv("MVD_ATTN_PIPE"); return e ? atoi(e) : 0; }();
+  static const int pipe = MVD_ENV_INT("MVD_ATTN_PIPE", 0);
+  g_last_attn[0] = NW; g_last_attn[1] = (int)(grid.x * grid.y * grid.z);
   if (a.prescaled && NW == 4 && NSUB == 2 && pipe) hipLaunchKernelGGL((attn_pipe_kernel<4>), grid, dim3(256), 0, s, a);
   else if (a.prescaled) hipLaunchKernelGGL((attn_kernel<NW, NSUB, true>), grid, dim3(64 * NW), 0, s, a);
   else                  hipLaunchKernelGGL((attn_kernel<NW, NSUB, false>), grid, dim3(64 * NW), 0, s, a);
@@ -528,6 +531,13 @@ int launch_nw(const MvdAttnArgs& a, int maxq, hipStream_t s) {
 }  // namespace
 
 int mvd_attention_pick_nw(const MvdAttnArgs& a);
+
+// out[2] = {waves per workgroup, workgroups} of the calling thread's last attention launch
+extern "C" int mvd_debug_last_attention_plan(int* out) {
+  if (!out) { mvd_set_error("last_attention_plan: null argument"); return -1; }
+  out[0] = g_last_attn[0]; out[1] = g_last_attn[1];
+  return 0;
+}
 
 int mvd_launch_attention(const MvdAttnArgs& a, hipStream_t s) {
   if (a.nprob < 1 || a.nprob > 2 || a.batch <= 0 || a.heads <= 0) { mvd_set_error("attention: bad problem count/batch/heads"); return -1; }
@@ -544,7 +554,7 @@ int mvd_launch_attention(const MvdAttnArgs& a, hipStream_t s) {
   // 128-key tiles are an experiment switch only (env MVD_ATTN_KV128=1): at 197 VGPRs / 64 KB LDS they run two
   // waves per SIMD instead of three and measured 3-4 % SLOWER than 64-key tiles on every UNet shape
   // (profiles/r01_probe_attention_kv128.log)
-  static const int kv128 = [] { const char* e = getenv("MVD_ATTN_KV128"); return e ? atoi(e) : 0; }();
+  static const int kv128 = MVD_ENV_INT("MVD_ATTN_KV128", 0);
   const bool big = kv128 != 0 && mink >= 256 && !a.prescaled;
   switch (mvd_attention_pick_nw(a)) {
     case 3: return launch_nw<8, 2>(a, maxq, s);
@@ -560,7 +570,7 @@ int mvd_attention_pick_nw(const MvdAttnArgs& a) {
   int maxq = 0;
   for (int i = 0; i < a.nprob; ++i) maxq = a.p[i].nq > maxq ? a.p[i].nq : maxq;
   const long heads_total = (long)a.heads * a.batch * a.nprob;
-  static const int force = [] { const char* e = getenv("MVD_ATTN_NW"); return e ? atoi(e) : -1; }();
+  static const int force = MVD_ENV_INT("MVD_ATTN_NW", -1);
   if (force >= 0) return force;
   if (maxq >= 128 && heads_total * ((maxq + 127) / 128) >= 512) return 2;
   if (maxq >= 64) return 1;

@@ -16,6 +16,15 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 #define MVD_DEVINL __device__ __forceinline__
 
+// Measurement switches exist in probe builds only (tools/build_variant.py <tag> -DMVD_PROBE): the product library
+// reads no environment variable on a launch path.
+#ifdef MVD_PROBE
+#include <stdlib.h>
+#define MVD_ENV_INT(name, dflt) ([] { const char* e_ = getenv(name); return e_ ? atoi(e_) : (dflt); }())
+#else
+#define MVD_ENV_INT(name, dflt) (dflt)
+#endif
+
 MVD_DEVINL float bf2f(bf16_t v) { return __builtin_bit_cast(float, (unsigned int)v << 16); }
 // plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN stays NaN)
 MVD_DEVINL bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }

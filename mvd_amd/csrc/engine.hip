@@ -61,6 +61,7 @@ struct mvd_engine {
   std::vector<bf16_t*> feat_keep;   // per feature: [ref_batch][hw][C] when kept
   int rc_batch = 0, rc_h = 0, rc_w = 0; bool rc_valid = false; bool rc_keep = false;
   float* cam_emb = nullptr; int cam_batch = 0;
+  bool share_encoder = false;       // N4: the encoder pass reads weight set 0 (base UNet == image-encoder UNet)
   ~mvd_engine() { for (hipEvent_t ev : ev_pool) (void)hipEventDestroy(ev); }
   std::vector<int> temb_off;        // per resnet offset into the fused time_emb_proj output
   int temb_total = 0;
@@ -134,7 +135,7 @@ struct Ctx {
     const int S = mvd_gemm_pick_splitk(g);
     const size_t mark = e->tmp.off;
     if (S > 1) { g.splitk = S; g.part = talloc<float>((size_t)S * g.M * g.N); }
-    static const bool trace = getenv("MVD_TRACE_GEMM") != nullptr;
+    static const bool trace = MVD_ENV_INT("MVD_TRACE_GEMM", 0) != 0;
     if (trace && !dry) fprintf(stderr, "gemm M=%d N=%d K=%d mode=%d nseg=%d geglu=%d cfg=%d splitk=%d\n", g.M, g.N, g.Ktot, g.seg[0].mode, g.nseg, g.geglu, mvd_gemm_pick_config(g), S);
     int r = 0;
     if (!dry) {
@@ -529,7 +530,8 @@ int camera_embed(Ctx& c, const float* src, const float* tgt, int cam_rows, const
 }
 
 // one modulator MLP: emb [B][D] -> processed FiLM scale/shift [B][dim]   (camera_encoder.py:215-222)
-int modulator(Ctx& c, const std::string& name, int dim, const float* emb, int B, float* sc, float* sh) {
+// (out_rows >= B: the processed scale/shift rows are replicated cyclically up to the sample batch)
+int modulator(Ctx& c, const std::string& name, int dim, const float* emb, int B, float* sc, float* sh, int out_rows = 0) {
   const mvd_config_t& cfg = c.e->cfg;
   const int D = cfg.cam_output_dim;
   float* mh = c.talloc<float>((size_t)B * (D / 2));
@@ -547,7 +549,7 @@ int modulator(Ctx& c, const std::string& name, int dim, const float* emb, int B,
   CHECK(mvd_launch_skinny_linear(emb, D, B, D, w0, 0, b0, D / 2, 0, mh, D / 2, c.s));
   CHECK(mvd_launch_layernorm_f32(mh, B, D / 2, 1e-5f, g1, b1, 1, mh2, c.s));
   CHECK(mvd_launch_skinny_linear(mh2, D / 2, B, D / 2, w3, 0, b3, 2 * dim, 0, raw, 2 * dim, c.s));
-  return mvd_launch_film_params(raw, B, dim, cfg.cam_modulation_strength, sc, sh, c.s);
+  return mvd_launch_film_params(raw, B, dim, cfg.cam_modulation_strength, sc, sh, out_rows > B ? out_rows : B, c.s);
 }
 
 // modulators addressed by the hooks: name -> dim (mvd_unet.py:63-80); "mid" exists as a parameter but
@@ -561,17 +563,21 @@ std::vector<std::pair<std::string, int>> modulator_dims(const mvd_config_t& cfg,
   return mods;
 }
 
+// The camera batch Bc may be smaller than the sample batch B (classifier-free guidance doubles the latents but not the
+// cameras, pipeline.py:141-152): the (Bc, C, 1, 1) scale/shift then broadcasts over the sample rows like torch does for
+// Bc == 1; for 1 < Bc < B (Bc | B) row b takes camera b % Bc, i.e. the [uncond | cond] halves share their cameras.
 int camera_path(Ctx& c, const mvd_forward_args_t& a, std::unordered_map<std::string, std::pair<float*, float*>>& ss) {
   const mvd_config_t& cfg = c.e->cfg;
   const int B = a.batch, D = cfg.cam_output_dim;
-  float* emb = c.aalloc<float>((size_t)B * D);
-  c.e->cam_emb = emb; c.e->cam_batch = B;
-  CHECK(camera_embed(c, a.source_camera, a.target_camera, a.cam_rows, a.fourier_proj, B, emb));
+  const int Bc = a.cam_batch > 0 ? a.cam_batch : B;
+  float* emb = c.aalloc<float>((size_t)Bc * D);
+  c.e->cam_emb = emb; c.e->cam_batch = Bc;
+  CHECK(camera_embed(c, a.source_camera, a.target_camera, a.cam_rows, a.fourier_proj, Bc, emb));
   for (auto& m : modulator_dims(cfg, false)) {
     float* sc = c.aalloc<float>((size_t)B * m.second);
     float* sh = c.aalloc<float>((size_t)B * m.second);
     const size_t mk = c.e->tmp.off;
-    CHECK(modulator(c, m.first, m.second, emb, B, sc, sh));
+    CHECK(modulator(c, m.first, m.second, emb, Bc, sc, sh, B));
     c.e->tmp.off = mk;
     ss[m.first] = {sc, sh};
   }
@@ -591,6 +597,10 @@ int forward_impl(mvd_engine* e, const mvd_forward_args_t& a, hipStream_t s, bool
     if (!e->ws_ptr) { mvd_set_error("forward: workspace not bound"); return -1; }
   }
   if (use_img && a.ref_batch <= 0) { mvd_set_error("forward: ref_batch must be > 0 with MVD_USE_IMAGE"); return -1; }
+  if (use_cam && a.cam_batch > 0 && (a.cam_batch > a.batch || a.batch % a.cam_batch)) { mvd_set_error("forward: camera batch %d must divide the sample batch %d", a.cam_batch, a.batch); return -1; }
+  // the input FiLM uses the 4-wide "output" modulator (mvd_unet.py:74-80, 256-258): any other in_channels is a broadcast
+  // error in the reference and would read past the [B][4] scale/shift rows here -- reject before any launch
+  if (use_cam && cfg.in_channels != 4) { mvd_set_error("forward: camera conditioning needs in_channels == 4 (the 'output' modulator is 4 wide), got %d", cfg.in_channels); return -1; }
 
   e->tmp.dry = e->act.dry = dry;
   e->tmp.off = e->tmp.high = 0;
@@ -628,7 +638,7 @@ int forward_impl(mvd_engine* e, const mvd_forward_args_t& a, hipStream_t s, bool
   // ---- reference image encoder pass (frozen UNet at t = 0, plain attention) -> adapter K/V
   if (use_img && !reuse) {
     const size_t tm = e->tmp.off, am = e->act.off;
-    c.set = 1;
+    c.set = e->share_encoder ? 0 : 1;
     const int Br = a.ref_batch;
     float* tz = c.talloc<float>(Br);
     if (!dry) CHECK((int)hipMemsetAsync(tz, 0, Br * sizeof(float), s));
@@ -799,21 +809,36 @@ int mvd_engine_profile_summary(mvd_engine_t* e, int cap, int* cls, int* launches
     if (j == n) { if (n == cap) continue; cls[n] = r.cls; launches[n] = 0; ms[n] = 0; flops[n] = 0; bytes[n] = 0; ++n; }
     launches[j] += 1; ms[j] += t; flops[j] += r.flops; bytes[j] += r.bytes;
   }
-  if (getenv("MVD_PROFILE_SHAPES")) {   // per-shape table on stderr (measurement aid)
-    struct Acc { int cls, M, N, K, tag, n; double ms, fl; };
-    std::vector<Acc> v;
-    for (auto& r : e->prof_recs) {
-      if (r.flops <= 0) continue;
-      float t = 0.f; (void)hipEventElapsedTime(&t, r.e0, r.e1);
-      size_t j = 0;
-      while (j < v.size() && !(v[j].cls == r.cls && v[j].M == r.M && v[j].N == r.N && v[j].K == r.K && v[j].tag == r.tag)) ++j;
-      if (j == v.size()) v.push_back({r.cls, r.M, r.N, r.K, r.tag, 0, 0.0, 0.0});
-      v[j].n++; v[j].ms += t; v[j].fl += r.flops;
-    }
-    for (auto& x : v) fprintf(stderr, "shape cls=%d M=%d N=%d K=%d tag=%d launches=%d ms=%.3f tflops=%.0f\n", x.cls, x.M, x.N, x.K, x.tag, x.n, x.ms, x.fl / x.ms / 1e9);
-  }
   e->prof_recs.clear(); e->ev_used = 0;
   return n;
+}
+
+int mvd_engine_profile_shapes(mvd_engine_t* e, char* buf, int cap) {
+  if (!e || !buf || cap <= 0) { mvd_set_error("profile_shapes: bad argument"); return -1; }
+  struct Acc { int cls, M, N, K, tag, n; double ms, fl; };
+  std::vector<Acc> v;
+  for (auto& r : e->prof_recs) {
+    if (hipEventSynchronize(r.e1) != hipSuccess) { mvd_set_error("profile_shapes: event sync failed"); return -2; }
+    float t = 0.f; (void)hipEventElapsedTime(&t, r.e0, r.e1);
+    size_t j = 0;
+    while (j < v.size() && !(v[j].cls == r.cls && v[j].M == r.M && v[j].N == r.N && v[j].K == r.K && v[j].tag == r.tag)) ++j;
+    if (j == v.size()) v.push_back({r.cls, r.M, r.N, r.K, r.tag, 0, 0.0, 0.0});
+    v[j].n++; v[j].ms += t; v[j].fl += r.flops;
+  }
+  int off = 0;
+  for (auto& x : v) {
+    const int w = snprintf(buf + off, (size_t)(cap - off), "cls=%d M=%d N=%d K=%d tag=%d launches=%d ms=%.3f tflops=%.0f\n", x.cls, x.M, x.N, x.K,
+                           x.tag, x.n, x.ms, x.ms > 0 ? x.fl / x.ms / 1e9 : 0.0);
+    if (w < 0 || off + w >= cap) break;
+    off += w;
+  }
+  return off;
+}
+
+int mvd_engine_share_encoder_weights(mvd_engine_t* e, int enable) {
+  if (!e) { mvd_set_error("share_encoder_weights: null engine"); return -1; }
+  e->share_encoder = enable != 0;
+  return 0;
 }
 
 int mvd_engine_num_features(mvd_engine_t* e) { return e ? (int)e->feats.size() : -1; }
@@ -833,11 +858,15 @@ int mvd_engine_encode_cameras(mvd_engine_t* e, const float* source_camera, const
                               int batch, const float* fourier_proj, float* out_emb, void* stream) {
   if (!e || !source_camera || !target_camera || !fourier_proj || !out_emb || batch <= 0 || (cam_rows != 3 && cam_rows != 4)) { mvd_set_error("encode_cameras: bad argument"); return -1; }
   if (!e->ws_ptr) { mvd_set_error("encode_cameras: workspace not bound"); return -1; }
+  {   // size the scratch with a dry pass: nothing is launched into a workspace that is too small
+    e->tmp.dry = true; e->tmp.off = e->tmp.high = 0;
+    Ctx d{e, nullptr, 0, true};
+    if (int r = camera_embed(d, source_camera, target_camera, cam_rows, fourier_proj, batch, out_emb)) return r;
+    if (e->tmp.high > (size_t)e->ws_bytes) { mvd_set_error("encode_cameras: workspace too small (%zu > %lld bytes)", e->tmp.high, (long long)e->ws_bytes); return -4; }
+  }
   e->tmp.dry = false; e->tmp.base = (char*)e->ws_ptr; e->tmp.cap = (size_t)e->ws_bytes; e->tmp.off = e->tmp.high = 0;
   Ctx c{e, (hipStream_t)stream, 0, false};
-  int r = camera_embed(c, source_camera, target_camera, cam_rows, fourier_proj, batch, out_emb);
-  if (!r && e->tmp.high > e->tmp.cap) { mvd_set_error("encode_cameras: workspace too small"); return -4; }
-  return r;
+  return camera_embed(c, source_camera, target_camera, cam_rows, fourier_proj, batch, out_emb);
 }
 
 // Standalone CameraEncoder.apply_modulation_to_tensor (camera_encoder.py:207-255) on an NCHW fp32 tensor.
@@ -850,13 +879,19 @@ int mvd_engine_apply_modulation(mvd_engine_t* e, const char* name, const float* 
   for (auto& m : modulator_dims(e->cfg, true)) if (m.first == name) dim = m.second;
   if (dim < 0) return 1;
   if (dim != channels) { mvd_set_error("apply_modulation: modulator '%s' has %d channels, tensor has %d", name, dim, channels); return -1; }
+  {   // dry sizing pass first (see encode_cameras)
+    e->tmp.dry = true; e->tmp.off = e->tmp.high = 0;
+    Ctx d{e, nullptr, 0, true};
+    float* sc0 = d.talloc<float>((size_t)batch * dim);
+    float* sh0 = d.talloc<float>((size_t)batch * dim);
+    if (int r = modulator(d, name, dim, emb, batch, sc0, sh0)) return r;
+    if (e->tmp.high > (size_t)e->ws_bytes) { mvd_set_error("apply_modulation: workspace too small (%zu > %lld bytes)", e->tmp.high, (long long)e->ws_bytes); return -4; }
+  }
   e->tmp.dry = false; e->tmp.base = (char*)e->ws_ptr; e->tmp.cap = (size_t)e->ws_bytes; e->tmp.off = e->tmp.high = 0;
   Ctx c{e, (hipStream_t)stream, 0, false};
   float* sc = c.talloc<float>((size_t)batch * dim);
   float* sh = c.talloc<float>((size_t)batch * dim);
-  int r = modulator(c, name, dim, emb, batch, sc, sh);
-  if (r) return r;
-  if (e->tmp.high > e->tmp.cap) { mvd_set_error("apply_modulation: workspace too small"); return -4; }
+  if (int r = modulator(c, name, dim, emb, batch, sc, sh)) return r;
   return mvd_launch_film_nchw_f32(x_nchw, batch, channels, hw, sc, sh, out_nchw, (hipStream_t)stream);
 }
 

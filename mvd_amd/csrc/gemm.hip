@@ -18,6 +18,7 @@
 // * blockIdx -> tile mapping is XCD-aware: consecutive tiles (same A rows, different N
 //   tile) land on the same XCD so the A slab is fetched from HBM once per XCD L2.
 #include <stdlib.h>
+#include <string.h>
 #include "kernels.h"
 
 namespace {
@@ -61,7 +62,8 @@ MVD_DEVINL void glds16(const void* gsrc, void* lds_wave_base) {
 // pipeline runs straight across tile boundaries -- the first slab of the next tile is already in flight while
 // the last slab of the current tile is multiplied and its epilogue runs, so short-K GEMMs (K = 320: five slabs)
 // do not pay a load-latency prologue per tile.
-template <class C, int AMODE, bool GLDS, bool SPLITK>
+// DBG: measurement instantiations (probe builds only, -DMVD_PROBE) honour a.dbg; product instantiations carry no such branches.
+template <class C, int AMODE, bool GLDS, bool SPLITK, bool DBG>
 __global__ __launch_bounds__(C::NT, C::MIN_WAVES) void gemm_kernel(const MvdGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(C::NT, C::MIN_WAVES) void gemm_kernel(const MvdGemm
 #pragma unroll
       for (int i = 0; i < C::A_IT; ++i) {
         const bf16_t* p = base + (size_t)a_m[i] * ld + col;
-        if (GLDS && (a.dbg & 4)) continue;   // measurement aid: no A traffic
+        if (DBG && GLDS && (a.dbg & 4)) continue;   // measurement aid: no A traffic
         if (GLDS) glds16(p, sa + (wave_chunk0 + i * C::NT) * 16);
         else ra[i] = *reinterpret_cast<const u32x4*>(p);
       }
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(C::NT, C::MIN_WAVES) void gemm_kernel(const MvdGemm
       const int row = lrow + i * C::ROWS_PER_IT;
       if (C::B_CHUNKS % C::NT == 0 || row < C::BN) {
         const bf16_t* p = a.W + (size_t)(ld_n0 + row) * a.ldw + lk * 64 + kc * 8;
-        if (GLDS && (a.dbg & 8)) continue;   // measurement aid: no W traffic
+        if (DBG && GLDS && (a.dbg & 8)) continue;   // measurement aid: no W traffic
         if (GLDS) glds16(p, sb + (wave_chunk0 + i * C::NT) * 16);
         else rb[i] = *reinterpret_cast<const u32x4*>(p);
       }
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(C::NT, C::MIN_WAVES) void gemm_kernel(const MvdGemm
           if (a.res) {
             v[0] += bflo(res_r[g][j][0]); v[1] += bfhi(res_r[g][j][0]); v[2] += bflo(res_r[g][j][1]); v[3] += bfhi(res_r[g][j][1]);
           }
-          if (!live || (a.dbg & 1)) continue;
+          if (!live || (DBG && (a.dbg & 1))) continue;
           if (a.out_f32) {
             *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + (size_t)m * a.ldo + n) = v;
           } else {
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(C::NT, C::MIN_WAVES) void gemm_kernel(const MvdGemm
 #pragma unroll
           for (int j = 0; j < C::TN; j += 2) {
             const f32x4 v = acc[i][j], g = acc[i][j + 1];    // packed rows: 16 value | 16 gate (bias already in)
-            if (!live || (a.dbg & 1)) continue;
+            if (!live || (DBG && (a.dbg & 1))) continue;
             const int no = (n0 + wn * C::WTN) / 2 + (j / 2) * 16 + fq * 4;
             u32x2 o = {pack2bf(v[0] * gelu_erf_f(g[0]), v[1] * gelu_erf_f(g[1])),
                        pack2bf(v[2] * gelu_erf_f(g[2]), v[3] * gelu_erf_f(g[3]))};
@@ -434,7 +436,7 @@ __global__ __launch_bounds__(C::NT, C::MIN_WAVES) void gemm_kernel(const MvdGemm
 #pragma unroll
         for (int j = 0; j < C::TN; ++j)
           wf[j] = *reinterpret_cast<const bf16x8*>(sb + swz_off(wn * C::WTN + j * 16 + fr, s2 * 4 + fq));
-        if (!(a.dbg & 2)) {
+        if (!(DBG && (a.dbg & 2))) {
 #pragma unroll
           for (int i = 0; i < C::TM; ++i)
 #pragma unroll
@@ -489,15 +491,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const MvdGemmArgs a)
 
 struct CfgInfo { int bm, bn, tn_even; };
 
-template <class C, int AMODE, bool GLDS, bool SPLITK>
-int launch_mode2(const MvdGemmArgs& a, hipStream_t s) {
+thread_local MvdLaunchPlan g_mvd_last_gemm = {-1, 1, 0, 0, 0};
+
+template <class C, int AMODE, bool GLDS, bool SPLITK, bool DBG>
+int launch_mode3(const MvdGemmArgs& a, hipStream_t s) {
   static int per_cu = 0;   // resident workgroups per CU for this instantiation (LDS- and VGPR-limited)
   if (!per_cu) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<C, AMODE, GLDS, SPLITK>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<C, AMODE, GLDS, SPLITK, DBG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     if (e != hipSuccess) { mvd_set_error("gemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return -2; }
     int nb = 0;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_kernel<C, AMODE, GLDS, SPLITK>, C::NT, C::LDS_BYTES);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_kernel<C, AMODE, GLDS, SPLITK, DBG>, C::NT, C::LDS_BYTES);
     if (e != hipSuccess || nb < 1) nb = 1;
     per_cu = nb > 4 ? 4 : nb;
   }
@@ -506,10 +510,19 @@ int launch_mode2(const MvdGemmArgs& a, hipStream_t s) {
   int grid = 256 * per_cu;
   const int ntiles = ntm * ntn * (a.splitk > 1 ? a.splitk : 1);
   if (ntiles < grid) grid = ((ntiles + 7) / 8) * 8;
-  hipLaunchKernelGGL((gemm_kernel<C, AMODE, GLDS, SPLITK>), dim3(grid), dim3(C::NT), C::LDS_BYTES, s, a);
+  g_mvd_last_gemm.tiles = ntiles; g_mvd_last_gemm.grid = grid; g_mvd_last_gemm.per_cu = per_cu;
+  hipLaunchKernelGGL((gemm_kernel<C, AMODE, GLDS, SPLITK, DBG>), dim3(grid), dim3(C::NT), C::LDS_BYTES, s, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { mvd_set_error("gemm launch: %s", hipGetErrorString(e)); return -3; }
   return 0;
+}
+
+template <class C, int AMODE, bool GLDS, bool SPLITK>
+int launch_mode2(const MvdGemmArgs& a, hipStream_t s) {
+#ifdef MVD_PROBE
+  if (a.dbg) return launch_mode3<C, AMODE, GLDS, SPLITK, true>(a, s);
+#endif
+  return launch_mode3<C, AMODE, GLDS, SPLITK, false>(a, s);
 }
 
 template <class C, int AMODE, bool GLDS>
@@ -547,17 +560,26 @@ constexpr int kNumCfgs = 9;
 
 extern "C" int mvd_gemm_num_configs(void) { return kNumCfgs; }
 
-// Tile choice (tools/tune_gemm.py sweep on MI355X, profiles/r01_tune_gemm_B32.log): 128x160 (4 waves, two
-// co-resident workgroups per CU) beats the 256-row tiles on every shape of the forward; fall to smaller tiles
-// until the grid has >= ~300 workgroups, else take the config with the most workgroups.
+// out[5] = {tile config, split-K factor, work items (tiles x split), workgroups launched, workgroups per CU} of the
+// calling thread's last GEMM / conv launch
+extern "C" int mvd_debug_last_gemm_plan(int* out) {
+  if (!out) { mvd_set_error("last_gemm_plan: null argument"); return -1; }
+  out[0] = g_mvd_last_gemm.cfg; out[1] = g_mvd_last_gemm.splitk; out[2] = g_mvd_last_gemm.tiles;
+  out[3] = g_mvd_last_gemm.grid; out[4] = g_mvd_last_gemm.per_cu;
+  return 0;
+}
+
+// Tile choice (tools/tune_gemm.py sweep on MI355X, profiles/r01_tune_gemm_B32_v2.log): the 256x320 tile wins wherever
+// its grid (times a split-K of at most 2) can occupy the 256 CUs; below that, fall through 128x160 -> 128x128 ->
+// 128x64 -> 64x64 until the grid has >= ~300 workgroups, else take the config with the most workgroups.
 int mvd_gemm_pick_config(const MvdGemmArgs& a) {
   // 256x320 tile with 128x80 wave tiles (49 FLOP per LDS-read byte): the kernel is LDS-bandwidth bound, so this
   // is the fastest shape whenever its tile grid -- times a split-K of up to 8 -- can occupy the 256 CUs
-  static const int use7 = [] { const char* e = getenv("MVD_GEMM_BIG"); return e ? atoi(e) : 1; }();
+  static const int use7 = MVD_ENV_INT("MVD_GEMM_BIG", 1);
   // (128x320 tiles instead of a two-way split-K at M = 8192: measured 1 % SLOWER end to end -- the W slab is
   //  re-fetched per 128 rows and the 64x80 wave tile reads more LDS per FLOP -- so it is an opt-in switch)
-  static const int split_min_slabs = [] { const char* e = getenv("MVD_GEMM_SPLIT_MINK"); return e ? atoi(e) / 64 : 64; }();
-  static const int use8 = [] { const char* e = getenv("MVD_GEMM_C8"); return e ? atoi(e) : 0; }();
+  static const int split_min_slabs = MVD_ENV_INT("MVD_GEMM_SPLIT_MINK", 4096) / 64;
+  static const int use8 = MVD_ENV_INT("MVD_GEMM_C8", 0);
   if (use7 && a.N % 320 == 0 && a.M >= 1024) {
     const long t7 = (long)((a.M + 255) / 256) * (a.N / 320);
     if (a.geglu) { if (t7 >= 200) return 6; }
@@ -615,21 +637,27 @@ int mvd_launch_gemm(const MvdGemmArgs& a, hipStream_t s, int force_cfg) {
   if (a.ldo < on || (a.ldo % 4) || (a.res && (a.ldres % 4))) { mvd_set_error("gemm: bad leading dims"); return -1; }
 
   // force_cfg: -1 = heuristic; 0..5 = tile config with register staging; 8..13 = same tiles with LDS-DMA staging
-  static const int default_glds = [] { const char* e = getenv("MVD_GEMM_GLDS"); return e ? atoi(e) : 1; }();
+  static const int default_glds = MVD_ENV_INT("MVD_GEMM_GLDS", 1);
   bool glds = default_glds != 0;
-  static const int dbg = [] { const char* e = getenv("MVD_GEMM_DEBUG"); return e ? atoi(e) : 0; }();
+#ifdef MVD_PROBE
+  static const int dbg = MVD_ENV_INT("MVD_GEMM_DEBUG", 0);
   if (dbg) const_cast<MvdGemmArgs&>(a).dbg = dbg;
+#endif
   int cfg = force_cfg;
-  // force_cfg 15 = the ring-pipelined 256x320 kernel (gemm_ring.hip); MVD_GEMM_RING=1 routes every plain 256x320 launch to it
-  static const int use_ring = [] { const char* e = getenv("MVD_GEMM_RING"); return e ? atoi(e) : 0; }();
+#ifdef MVD_PROBE
+  // probe builds only: force_cfg 15 = the ring-pipelined 256x320 experiment (gemm_ring.hip, not part of the product
+  // library); MVD_GEMM_RING=1 routes every plain 256x320 launch to it
+  static const int use_ring = MVD_ENV_INT("MVD_GEMM_RING", 0);
   if (cfg == 15) {
     if (a.N % 320 || a.geglu || a.out_f32) { mvd_set_error("gemm: the ring kernel needs N %% 320 == 0, bf16 output, no GEGLU"); return -1; }
     return mvd_launch_gemm_ring(a, s);
   }
+#endif
   if (cfg == 14) { glds = true; cfg = 8; }       // force_cfg 14 = the 128x320 tile (LDS-DMA only)
-  else if (cfg >= 8) { glds = true; cfg -= 8; } else if (cfg >= 0 && cfg < 6) { glds = false; }
+  else if (cfg >= 8 && cfg < 14) { glds = true; cfg -= 8; } else if (cfg >= 0 && cfg < 6) { glds = false; }
   if (cfg < 0) cfg = mvd_gemm_pick_config(a);
   if (cfg < 0 || cfg >= kNumCfgs || a.N % kCfgs[cfg].bn || (a.geglu && !kCfgs[cfg].tn_even)) { mvd_set_error("gemm: no tile config for N=%d geglu=%d cfg=%d", a.N, a.geglu, cfg); return -1; }
+  g_mvd_last_gemm.cfg = cfg; g_mvd_last_gemm.splitk = a.splitk > 1 ? a.splitk : 1;
   switch (cfg) {
     case 0: return launch_cfg<C0>(a, s, glds);
     case 1: return launch_cfg<C1>(a, s, glds);
@@ -640,7 +668,9 @@ int mvd_launch_gemm(const MvdGemmArgs& a, hipStream_t s, int force_cfg) {
       if (!a.geglu || a.seg[0].mode != MVD_A_DENSE || a.splitk > 1) { mvd_set_error("gemm: tile config 6 is GEGLU-only"); return -1; }
       return launch_mode2<C6, 0, true, false>(a, s);
     case 7:
+#ifdef MVD_PROBE
       if (use_ring && !a.out_f32 && !a.dbg) return mvd_launch_gemm_ring(a, s);
+#endif
       return launch_cfg<C7>(a, s, true);
     case 8: return launch_cfg<C8>(a, s, true);
     default: return launch_cfg<C5>(a, s, glds);
@@ -661,6 +691,13 @@ int mvd_gemm_pick_splitk(const MvdGemmArgs& a) {
   if (s > nkt / 8) s = nkt / 8;
   if (s > 4) s = 4;                                           // partial-sum traffic grows with the split
   return s < 2 ? 1 : (int)s;
+}
+
+// the split factor the engine's schedule would use for a GEMM / conv of this size (tests drive mvd_op_* with it)
+extern "C" int mvd_debug_pick_splitk(int m, int n, int k, int geglu) {
+  MvdGemmArgs a; memset(&a, 0, sizeof(a));
+  a.M = m; a.N = n; a.Ktot = k; a.geglu = geglu;
+  return mvd_gemm_pick_splitk(a);
 }
 
 int mvd_launch_splitk_reduce(const MvdGemmArgs& a, hipStream_t s) {

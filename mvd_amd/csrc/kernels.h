@@ -41,11 +41,13 @@ struct MvdGemmArgs {
   int out_f32;            // 1: fp32 output, else bf16
   int splitk;             // > 1: K is split over `splitk` work items per tile; raw fp32 partial tiles go to `part`
   float* part;            // [splitk][M][N] fp32 partials (then mvd_launch_splitk_reduce applies the epilogue)
-  int dbg;                // measurement only (env MVD_GEMM_DEBUG): bit0 skip the output stores, bit1 skip the MFMAs
+  int dbg;                // probe builds only (-DMVD_PROBE, env MVD_GEMM_DEBUG): bit0 skip the output stores, bit1 skip the MFMAs
 };
 
 int mvd_launch_gemm(const MvdGemmArgs& a, hipStream_t s, int force_cfg = -1);
-// ring-pipelined 256x320 kernel (gemm_ring.hip); arguments already validated by mvd_launch_gemm
+// what the calling thread's last mvd_launch_gemm launched (tests assert that the persistent multi-tile path ran)
+struct MvdLaunchPlan { int cfg, splitk, tiles, grid, per_cu; };
+// ring-pipelined 256x320 experiment (gemm_ring.hip, linked into probe builds only); arguments already validated by mvd_launch_gemm
 int mvd_launch_gemm_ring(const MvdGemmArgs& a, hipStream_t s);
 // sum the split-K partials and apply the GEMM epilogue (bias, row vector, alpha, residual) -> out
 int mvd_launch_splitk_reduce(const MvdGemmArgs& a, hipStream_t s);
@@ -112,8 +114,9 @@ int mvd_launch_timestep_embedding(const float* t, int batch, int dim, float* y, 
 // rflat [batch][9], enc [batch][6*nfreq] (before the random projection)
 int mvd_launch_camera_features(const float* src, const float* tgt, int batch, int cam_rows, int nfreq,
                                float max_freq, float* rflat, float* enc, hipStream_t s);
-// FiLM post-processing: raw [batch][2*dim] -> scale = 2*sigmoid(raw[:dim])*k, shift = raw[dim:]*k
-int mvd_launch_film_params(const float* raw, int batch, int dim, float strength, float* scale, float* shift,
+// FiLM post-processing: raw [batch][2*dim] -> scale = 2*sigmoid(raw[:dim])*k, shift = raw[dim:]*k; writes out_rows
+// (>= batch) rows, row r from input row r % batch (camera batch broadcast over a larger sample batch)
+int mvd_launch_film_params(const float* raw, int batch, int dim, float strength, float* scale, float* shift, int out_rows,
                            hipStream_t s);
 
 // FiLM on an NCHW fp32 tensor (standalone CameraEncoder.apply_modulation); scale/shift [batch][c]

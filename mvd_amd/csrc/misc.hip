@@ -289,11 +289,11 @@ __global__ void camera_features_kernel(const float* __restrict__ src, const floa
   }
 }
 
-__global__ void film_params_kernel(const float* __restrict__ raw, int dim, float strength, float* __restrict__ scale,
+__global__ void film_params_kernel(const float* __restrict__ raw, int batch, int dim, float strength, float* __restrict__ scale,
                                    float* __restrict__ shift, int total) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const int b = i / dim, ch = i % dim;
+  const int b = (i / dim) % batch, ch = i % dim;   // output rows beyond `batch` repeat the inputs cyclically
   const float s = raw[(size_t)b * 2 * dim + ch], t = raw[(size_t)b * 2 * dim + dim + ch];
   scale[i] = 2.0f * strength / (1.0f + expf(-s));
   shift[i] = t * strength;
@@ -407,7 +407,7 @@ int mvd_launch_skinny_linear(const float* x, int ldx, int batch, int k, const vo
   // rotation input and misaligned views); two features per wave
   const int kv = wbf16 ? 8 : 4;
   const bool vec = (k % kv) == 0 && (ldx % 4) == 0 && (((uintptr_t)x | (uintptr_t)w) & 15) == 0;
-  static const int use_vec = [] { const char* e = getenv("MVD_SKINNY_VEC"); return e ? atoi(e) : 1; }();
+  static const int use_vec = MVD_ENV_INT("MVD_SKINNY_VEC", 1);
   if (vec && use_vec) {
     constexpr int F = 2;
     const dim3 g(nblk(n, 4 * F));
@@ -433,10 +433,11 @@ int mvd_launch_camera_features(const float* src, const float* tgt, int batch, in
   return check("camera_features");
 }
 
-int mvd_launch_film_params(const float* raw, int batch, int dim, float strength, float* scale, float* shift, hipStream_t s) {
-  if (!raw || !scale || !shift || batch <= 0 || dim <= 0) { mvd_set_error("film_params: bad arguments"); return -1; }
-  const int total = batch * dim;
-  hipLaunchKernelGGL(film_params_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, raw, dim, strength, scale, shift, total);
+int mvd_launch_film_params(const float* raw, int batch, int dim, float strength, float* scale, float* shift, int out_rows,
+                           hipStream_t s) {
+  if (!raw || !scale || !shift || batch <= 0 || dim <= 0 || out_rows < batch) { mvd_set_error("film_params: bad arguments"); return -1; }
+  const int total = out_rows * dim;
+  hipLaunchKernelGGL(film_params_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, raw, batch, dim, strength, scale, shift, total);
   return check("film_params");
 }
 

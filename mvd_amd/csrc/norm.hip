@@ -14,12 +14,16 @@ MVD_DEVINL u32x4 pack8(const float* f) {
   return u32x4{pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7])};
 }
 
-// ---------------------------------------------------------------- GroupNorm: partial sums
+// ---------------------------------------------------------------- GroupNorm: partial statistics
 // grid (nchunk, batch); block = vec*R threads (vec = C/8 channel vectors, R rows in flight).
-// Deterministic: per-thread channel sums -> LDS -> fixed-order per-group reduction.
+// Deterministic (fixed-order reductions) and CANCELLATION-SAFE: a thread accumulates sum / sum of squares of
+// (x - shift) with shift = its own first element, turns them into (count, mean, M2 = sum (x - mean)^2), and partials
+// are merged with the parallel-variance formula  M2 = sum_i M2_i + n_i (mean_i - mean)^2  (Chan et al.) -- never
+// E[x^2] - mean^2, which loses every digit once |mean| >> std (trained SD channels).
+// ws holds per (batch, chunk, group): mean, M2 (the count follows from the chunk geometry).
 __global__ void gn_stats_kernel(const bf16_t* __restrict__ x0, const bf16_t* __restrict__ x1, int c0, int c1, int hw,
                                 int groups, int rows_per_chunk, int R, float* __restrict__ ws) {
-  extern __shared__ __attribute__((aligned(16))) float sh[];  // [R][C][2]
+  extern __shared__ __attribute__((aligned(16))) float sh[];  // [R][C][2] = (mean, M2) per thread and channel
   const int C = c0 + c1, vec = C >> 3;
   const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
   const int v = threadIdx.x % vec, r = threadIdx.x / vec;
@@ -29,37 +33,61 @@ __global__ void gn_stats_kernel(const bf16_t* __restrict__ x0, const bf16_t* __r
   const bool first = ch < c0;
   const bf16_t* src = first ? x0 + (size_t)b * hw * c0 + ch : x1 + (size_t)b * hw * c1 + (ch - c0);
   const int ld = first ? c0 : c1;
-  float s[8], q[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
   if (r < R) {
+    float s[8], q[8], sft[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; sft[j] = 0.f; }
+    int n = 0;
+    if (row0 + r < row1) unpack8(*reinterpret_cast<const u32x4*>(src + (size_t)(row0 + r) * ld), sft);
     for (int row = row0 + r; row < row1; row += R) {
       float f[8];
       unpack8(*reinterpret_cast<const u32x4*>(src + (size_t)row * ld), f);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { s[j] += f[j]; q[j] = fmaf(f[j], f[j], q[j]); }
+      for (int j = 0; j < 8; ++j) { const float d = f[j] - sft[j]; s[j] += d; q[j] = fmaf(d, d, q[j]); }
+      ++n;
     }
+    const float inv = n ? 1.0f / (float)n : 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      sh[(r * C + ch + j) * 2] = s[j];
-      sh[(r * C + ch + j) * 2 + 1] = q[j];
+      sh[(r * C + ch + j) * 2] = sft[j] + s[j] * inv;                       // mean of this thread's samples
+      sh[(r * C + ch + j) * 2 + 1] = fmaxf(q[j] - s[j] * s[j] * inv, 0.f);  // their M2
     }
   }
   __syncthreads();
   const int cg = C / groups;
-  if (threadIdx.x < groups * 2) {
-    const int g = threadIdx.x >> 1, which = threadIdx.x & 1;
-    float acc = 0.f;
-    for (int rr = 0; rr < R; ++rr)
-      for (int cc = 0; cc < cg; ++cc) acc += sh[(rr * C + g * cg + cc) * 2 + which];
-    ws[(((size_t)b * nchunk + chunk) * groups + g) * 2 + which] = acc;
+  if (threadIdx.x < groups) {
+    const int g = threadIdx.x;
+    const int nrows = row1 - row0;
+    // thread r of the row loop saw rows row0 + r, row0 + r + R, ...: n_r = ceil((nrows - r) / R)
+    float tot = 0.f, msum = 0.f;
+    for (int rr = 0; rr < R; ++rr) {
+      const int nr = nrows > rr ? (nrows - rr + R - 1) / R : 0;
+      if (!nr) continue;
+      float a = 0.f;
+      for (int cc = 0; cc < cg; ++cc) a += sh[(rr * C + g * cg + cc) * 2];
+      msum += a * (float)nr;
+      tot += (float)nr * (float)cg;
+    }
+    const float mean = tot > 0.f ? msum / tot : 0.f;
+    float m2 = 0.f;
+    for (int rr = 0; rr < R; ++rr) {
+      const int nr = nrows > rr ? (nrows - rr + R - 1) / R : 0;
+      if (!nr) continue;
+      for (int cc = 0; cc < cg; ++cc) {
+        const float d = sh[(rr * C + g * cg + cc) * 2] - mean;
+        m2 += sh[(rr * C + g * cg + cc) * 2 + 1] + (float)nr * d * d;
+      }
+    }
+    float* o = ws + (((size_t)b * nchunk + chunk) * groups + g) * 2;
+    o[0] = mean; o[1] = m2;
   }
 }
 
 // ---------------------------------------------------------------- GroupNorm: apply (+SiLU)
 __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x0, const bf16_t* __restrict__ x1,
                                                         int c0, int c1, int hw, int groups, int nchunk_stats,
-                                                        float eps, const float* __restrict__ gamma,
+                                                        int rows_per_chunk_stats, float eps,
+                                                        const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int silu,
                                                         const float* __restrict__ ws, int rows_per_blk,
                                                         bf16_t* __restrict__ y) {
@@ -71,23 +99,28 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
   float* s_a = sh + 2 * groups;
   float* s_b = s_a + C;
   {
-    // fixed-order (deterministic) reduction of the partial sums: 8 lanes per group, then an xor-shuffle tree
+    // fixed-order (deterministic) merge of the per-chunk (count, mean, M2): 8 lanes per group, xor-shuffle trees;
+    // pass 1 the global mean, pass 2 M2 = sum M2_c + n_c (mean_c - mean)^2
     const int g = threadIdx.x >> 3, part = threadIdx.x & 7;
-    float s = 0.f, q = 0.f;
-    if (g < groups) {
-      for (int ck = part; ck < nchunk_stats; ck += 8) {
-        s += ws[(((size_t)b * nchunk_stats + ck) * groups + g) * 2];
-        q += ws[(((size_t)b * nchunk_stats + ck) * groups + g) * 2 + 1];
-      }
-    }
+    const float* wg = ws + ((size_t)b * nchunk_stats * groups + (g < groups ? g : 0)) * 2;
+    auto rows_of = [&](int ck) { return min(hw, (ck + 1) * rows_per_chunk_stats) - ck * rows_per_chunk_stats; };
+    float s = 0.f;
+    if (g < groups)
+      for (int ck = part; ck < nchunk_stats; ck += 8) s += wg[(size_t)ck * groups * 2] * (float)rows_of(ck);
 #pragma unroll
-    for (int o = 4; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    for (int o = 4; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)hw;
+    float q = 0.f;
+    if (g < groups)
+      for (int ck = part; ck < nchunk_stats; ck += 8) {
+        const float d = wg[(size_t)ck * groups * 2] - mean;
+        q += wg[(size_t)ck * groups * 2 + 1] + (float)rows_of(ck) * (float)cg * d * d;
+      }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
     if (g < groups && part == 0) {
-      const float n = (float)hw * (float)cg;
-      const float mean = s / n;
-      const float var = fmaxf(q / n - mean * mean, 0.f);
       s_mean[g] = mean;
-      s_rstd[g] = rsqrtf(var + eps);
+      s_rstd[g] = rsqrtf(q / ((float)hw * (float)cg) + eps);
     }
   }
   __syncthreads();
@@ -269,7 +302,7 @@ int mvd_launch_groupnorm(const bf16_t* x0, const bf16_t* x1, int c0, int c1, int
   const int threads = ((vec * R + 63) / 64) * 64;
   // enough workgroups to cover the chip even at batch 1: >= ~512 blocks when the map is large enough,
   // at least 8 rows per chunk
-  static const int rows_target = [] { const char* e = getenv("MVD_GN_ROWS"); return e ? atoi(e) : 128; }();
+  static const int rows_target = MVD_ENV_INT("MVD_GN_ROWS", 128);
   int nchunk = hw / rows_target;
   if ((long)nchunk * batch < 512) nchunk = (512 + batch - 1) / batch;
   if (nchunk > hw / 8) nchunk = hw / 8;
@@ -280,7 +313,7 @@ int mvd_launch_groupnorm(const bf16_t* x0, const bf16_t* x1, int c0, int c1, int
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, batch), dim3(threads), sh1, s, x0, x1, c0, c1, hw, groups, rpc, R, ws);
   if (int r = check_launch("gn_stats")) return r;
   // apply: ~16K elements per block, fewer when that would leave CUs idle (small batch)
-  static const long per_blk_env = [] { const char* e = getenv("MVD_GN_APPLY_ELEMS"); return e ? atol(e) : 65536L; }();
+  static const long per_blk_env = MVD_ENV_INT("MVD_GN_APPLY_ELEMS", 65536);
   long per_blk = per_blk_env;
   const long total_el = (long)batch * hw * C;
   if (total_el / per_blk < 1024) per_blk = total_el / 1024 < 2048 ? 2048 : total_el / 1024;
@@ -289,7 +322,7 @@ int mvd_launch_groupnorm(const bf16_t* x0, const bf16_t* x1, int c0, int c1, int
   if (rows_per_blk > hw) rows_per_blk = hw;
   const int nblk = (hw + rows_per_blk - 1) / rows_per_blk;
   const size_t sh2 = (size_t)(2 * groups + 2 * C) * sizeof(float);
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, batch), dim3(256), sh2, s, x0, x1, c0, c1, hw, groups, nchunk, eps, gamma,
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, batch), dim3(256), sh2, s, x0, x1, c0, c1, hw, groups, nchunk, rpc, eps, gamma,
                      beta, silu, ws, rows_per_blk, y);
   return check_launch("gn_apply");
 }

@@ -12,16 +12,74 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend: str = "nccl") -> tuple:
-    """(rank, world, local_rank); initialises torch.distributed when WORLD_SIZE > 1."""
+def init_from_env(backend: str = "nccl", set_device: bool = True) -> tuple:
+    """(rank, world, local_rank); initialises torch.distributed when WORLD_SIZE > 1.  With the RCCL backend the rank's
+    GPU is selected BEFORE the process group exists, so the communicator is created on the right device."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if set_device and backend == "nccl" and torch.cuda.is_available():
+        torch.cuda.set_device(local)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {}
+        if backend == "nccl" and torch.cuda.is_available():
+            kw["device_id"] = torch.device("cuda", local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
+
+
+ARENA_ALIGN = 256      # bytes; every slot of an arena starts on this boundary (the engine needs >= 16)
+
+
+def pack_into_arenas(tensors: Dict[str, torch.Tensor]) -> tuple:
+    """Move ``tensors`` (name -> contiguous tensor, one device) into ONE flat buffer per dtype.
+
+    Returns ``(arenas, views)``: ``arenas`` maps dtype -> flat tensor, ``views`` maps name -> a view of its arena with
+    the original shape (256-byte aligned).  A broadcast of the packed weights is then a handful of large in-place
+    ``dist.broadcast`` calls on slices of the arenas -- no ``torch.cat`` staging copy and no copy-back."""
+    arenas: Dict[torch.dtype, torch.Tensor] = {}
+    views: Dict[str, torch.Tensor] = {}
+    by_dtype: Dict[torch.dtype, List[str]] = {}
+    for name in sorted(tensors):
+        by_dtype.setdefault(tensors[name].dtype, []).append(name)
+    for dtype, names in by_dtype.items():
+        esz = tensors[names[0]].element_size()
+        step = ARENA_ALIGN // esz
+        offs, total = [], 0
+        for n in names:
+            offs.append(total)
+            total += (tensors[n].numel() + step - 1) // step * step
+        arena = torch.zeros(total, dtype=dtype, device=tensors[names[0]].device)
+        for n, off in zip(names, offs):
+            t = tensors[n]
+            v = arena[off:off + t.numel()].view(t.shape)
+            v.copy_(t)
+            views[n] = v
+        arenas[dtype] = arena
+    return arenas, views
+
+
+def broadcast_arenas(arenas: Iterable[torch.Tensor], src: int = 0, bucket_bytes: int = 256 << 20) -> Dict[str, float]:
+    """In-place broadcast of flat buffers in slices of ``bucket_bytes`` (a ring broadcast over xGMI is per-link bound,
+    so few large messages; slices rather than one call keep the transfers pipelined with each other's completion)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return dict(bytes=0, seconds=0.0, buckets=0)
+    t0 = time.perf_counter()
+    total = nb = 0
+    cuda = False
+    for a in arenas:
+        cuda = cuda or a.is_cuda
+        step = max(1, bucket_bytes // a.element_size())
+        for off in range(0, a.numel(), step):
+            chunk = a[off:off + step]
+            dist.broadcast(chunk, src)
+            total += chunk.numel() * chunk.element_size()
+            nb += 1
+    if cuda:
+        torch.cuda.synchronize()
+    return dict(bytes=total, seconds=time.perf_counter() - t0, buckets=nb)
 
 
 def shard_range(n_items: int, rank: int, world: int) -> range:
@@ -72,11 +130,14 @@ def broadcast_tensors(tensors: Sequence[torch.Tensor], src: int = 0, bucket_byte
     return dict(bytes=total, seconds=time.perf_counter() - t0, buckets=nb)
 
 
-def broadcast_engine_weights(engine, src: int = 0) -> Dict[str, float]:
-    """Broadcast every packed device weight of ``engine`` (both weight sets) from ``src`` in place;
-    the engine keeps pointing at the same buffers."""
-    ts = [t for d in engine._weights for _, t in sorted(d.items())]
-    return broadcast_tensors(ts, src)
+def broadcast_engine_weights(engine, src: int = 0, bucket_bytes: int = 256 << 20) -> Dict[str, float]:
+    """Broadcast every packed device weight of ``engine`` (both weight sets) from ``src`` in place.  The engine's
+    weights are first consolidated into one arena per dtype (``engine.consolidate_weights()``; a no-op when already
+    done), so each bucket is a slice of an arena: nothing is staged or copied back."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return dict(bytes=0, seconds=0.0, buckets=0)
+    engine.consolidate_weights()
+    return broadcast_arenas(engine._arenas.values(), src, bucket_bytes)
 
 
 def max_over_ranks(value: float, device) -> float:

@@ -42,6 +42,8 @@ class MVDEngine:
         L.call("mvd_engine_create", C.byref(c), C.byref(h))
         self._h = h
         self._weights: List[Dict[str, torch.Tensor]] = [{}, {}]   # keeps packed tensors alive
+        self._arenas: Dict[torch.dtype, torch.Tensor] = {}        # one flat buffer per dtype once consolidated
+        self._arenas_stale = True
         self._ws = None
         self._rc = None
         self._ws_key = None
@@ -61,6 +63,7 @@ class MVDEngine:
             dt = {torch.float32: 0, torch.bfloat16: 1}[t.dtype]
             L.call("mvd_engine_set_weight", self._h, set_id, slot.encode(), _ptr(t), t.numel(), dt)
         self._weights[set_id].update(packed)
+        self._arenas_stale = True
 
     def load_base(self, sd: Dict[str, torch.Tensor], adapter: bool, ref_scale: float):
         """``sd``: diffusers keys of base_unet (+ ``...processor.*`` adapter keys when ``adapter``)."""
@@ -74,6 +77,36 @@ class MVDEngine:
     def load_image_encoder(self, sd: Dict[str, torch.Tensor]):
         with torch.no_grad():
             self._register(1, pack_unet(sd, self.cfg, self.device, False))
+        self.share_encoder_weights(False)
+
+    def share_encoder_weights(self, enable: bool = True):
+        """N4 (training.py:60-65): the image encoder's UNet equals the frozen base UNet -> the encoder pass reads weight
+        set 0 and the second packed weight set (1.73 GB bf16) is dropped."""
+        L.call("mvd_engine_share_encoder_weights", self._h, int(enable))
+        if enable:
+            L.call("mvd_engine_clear_weights", self._h, 1)
+            self._weights[1] = {}
+            self._arenas_stale = True
+
+    def consolidate_weights(self):
+        """Re-home every registered weight (both sets) in ONE flat device buffer per dtype and re-register the slots
+        (same contents, 256-byte aligned views).  Makes the multi-GPU start-up broadcast a few large in-place
+        transfers (mvd_amd/distributed.py) and the weights one contiguous HBM region."""
+        if self._arenas and not self._arenas_stale:
+            return
+        from .distributed import pack_into_arenas
+        flat = {f"{i}/{k}": t for i, d in enumerate(self._weights) for k, t in d.items()}
+        if not flat:
+            return
+        self._arenas, views = pack_into_arenas(flat)
+        for name, v in views.items():
+            i, k = name.split("/", 1)
+            self._weights[int(i)][k] = v
+        for i, d in enumerate(self._weights):
+            for slot, t in d.items():
+                dt = {torch.float32: 0, torch.bfloat16: 1}[t.dtype]
+                L.call("mvd_engine_set_weight", self._h, i, slot.encode(), _ptr(t), t.numel(), dt)
+        self._arenas_stale = False
 
     def weight_bytes(self) -> int:
         return sum(t.numel() * t.element_size() for d in self._weights for t in d.values())
@@ -100,6 +133,7 @@ class MVDEngine:
         L.call("mvd_engine_bind_workspace", self._h, _ptr(self._ws), self._ws.numel(),
                _ptr(self._rc) if rc else None, self._rc.numel() if rc else 0)
         self._ws_key = key
+        self._ref_valid = None      # re-binding drops the engine's cached reference K/V
 
     # ------------------------------------------------------------------ forward
     def forward(self, sample: torch.Tensor, timesteps: torch.Tensor, text: torch.Tensor,
@@ -132,10 +166,13 @@ class MVDEngine:
         if use_cam:
             if source_camera is None or fourier_proj is None:
                 raise L.MvdError("camera conditioning needs source_camera, target_camera and fourier_proj")
-            if source_camera.shape[0] != B or target_camera.shape[0] != B:
-                raise L.MvdError("camera batch must equal the sample batch")
+            Bc = target_camera.shape[0]
+            if source_camera.shape[0] != Bc or Bc < 1 or Bc > B or B % Bc:
+                raise L.MvdError(f"camera batch {tuple(source_camera.shape)} / {tuple(target_camera.shape)} must be equal "
+                                 f"and divide the sample batch {B}")
             a.source_camera, a.target_camera = source_camera.data_ptr(), target_camera.data_ptr()
             a.cam_rows = source_camera.shape[1]
+            a.cam_batch = Bc        # Bc < B: the FiLM scale/shift broadcast over the sample rows (CFG, pipeline.py:141-152)
             a.fourier_proj = fourier_proj.data_ptr()
             flags |= L.MVD_USE_CAMERA
         if use_img:
@@ -151,7 +188,13 @@ class MVDEngine:
         a.ref_batch, a.flags = ref_batch, flags
         a.out = out.data_ptr()
         L.call("mvd_unet_forward", self._h, C.byref(a), _stream())
+        if use_img and not reuse_ref:
+            self._ref_valid = (B, H, W, Lt, ref_batch)
         return out
+
+    def reference_cache_valid(self, batch, h, w, text_len, ref_batch) -> bool:
+        """True when the engine still holds reference K/V computed for exactly this shape (Q5 reuse is then legal)."""
+        return getattr(self, "_ref_valid", None) == (batch, h, w, text_len, ref_batch)
 
     # ------------------------------------------------------------------ measurement
     PROFILE_CLASSES = {0: "gemm_256x160", 1: "gemm_256x128", 2: "gemm_128x160", 3: "gemm_128x128", 4: "gemm_128x64",
@@ -160,6 +203,14 @@ class MVDEngine:
 
     def set_profiling(self, enable: bool):
         L.call("mvd_engine_set_profiling", self._h, int(enable))
+
+    def profile_shapes(self) -> str:
+        """Per-shape table of the recorded launches (call before profile_summary, which resets the records)."""
+        buf = C.create_string_buffer(1 << 18)
+        n = L.lib().mvd_engine_profile_shapes(self._h, buf, len(buf))
+        if n < 0:
+            raise L.MvdError(f"profile_shapes: {L.last_error()}")
+        return buf.raw[:n].decode()
 
     def profile_summary(self):
         """{class name: dict(launches, ms, flops, bytes)} of the launches recorded since the last call."""

@@ -111,7 +111,7 @@ class MultiViewUNet(nn.Module):
                  img_ref_scale: float = 0.3, cam_modulation_strength: float = 0.2, cam_output_dim: int = 1024,
                  cam_hidden_dim: int = 512, use_camera_conditioning: bool = True, use_image_conditioning: bool = True,
                  simple_cam_encoder: bool = False, *, unet_config: Optional[UNetConfig] = None, init: str = "default",
-                 cache_reference: bool = False):
+                 cache_reference: bool = False, dedup_encoder_weights="auto"):
         super().__init__()
         self.use_camera_conditioning = use_camera_conditioning
         self.use_image_conditioning = use_image_conditioning
@@ -119,6 +119,10 @@ class MultiViewUNet(nn.Module):
         self.simple_cam_encoder = simple_cam_encoder
         self.cam_modulation_strength = cam_modulation_strength
         self.cache_reference = cache_reference           # Q5: reuse reference K/V when inputs are the same tensors
+        # N4 (training.py:60-65, train_config.yaml:43): with a frozen base UNet the image encoder holds the same weights;
+        # "auto" compares the two state dicts when the engine packs them and keeps ONE packed copy if they are equal
+        self.dedup_encoder_weights = dedup_encoder_weights
+        self.encoder_weights_shared = False
 
         cfg = _resolve_config(pretrained_model_name_or_path, unet_config)
         self.unet_config = cfg
@@ -151,6 +155,7 @@ class MultiViewUNet(nn.Module):
         self._engine = None
         self._dirty = True
         self._ref_key = None
+        self._ref_hold = None              # strong references to the tensors _ref_key was computed from
         self.current_camera_embedding = None
         self.fourier_projection = None     # set to a (cam_dim, 6*nfreq) tensor to pin Q1's per-call random matrix
 
@@ -213,11 +218,25 @@ class MultiViewUNet(nn.Module):
                 self._engine.load_camera(self.camera_encoder.state_dict())
                 self.camera_encoder._engine = self._engine
                 self.camera_encoder._sync = self._sync_engine
+            self.encoder_weights_shared = False
             if self.image_encoder is not None:
-                self._engine.load_image_encoder(self.image_encoder.unet.state_dict())
+                esd = self.image_encoder.unet.state_dict()
+                share = self.dedup_encoder_weights
+                if share == "auto":
+                    share = all(k in sd and sd[k].shape == v.shape and torch.equal(sd[k], v.to(sd[k].device)) for k, v in esd.items())
+                if share:
+                    self._engine.share_encoder_weights(True)
+                    self.encoder_weights_shared = True
+                else:
+                    self._engine.load_image_encoder(esd)
             self._dirty = False
-            self._ref_key = None
+            self.reset_reference_cache()
         return self._engine
+
+    def reset_reference_cache(self):
+        """Forget the cached reference K/V (Q5): the next forward with image conditioning re-runs the encoder pass."""
+        self._ref_key = None
+        self._ref_hold = None
 
     @staticmethod
     def _f32(t: torch.Tensor, dev) -> torch.Tensor:
@@ -231,7 +250,7 @@ class MultiViewUNet(nn.Module):
         B = lat.shape[0]
         dummy_t = torch.zeros(B, device=dev, dtype=torch.float32)
         eng.forward(lat, dummy_t, txt, source_latents=lat, encoder_text=txt, keep_features=True)
-        self._ref_key = None
+        self.reset_reference_cache()
         return eng.features()
 
     # ------------------------------------------------------------------ mvd_unet.py:179-338
@@ -269,16 +288,21 @@ class MultiViewUNet(nn.Module):
                 enc_text = text[bs:]
             elif text.shape[0] > bs:                                   # :284-285
                 enc_text = text[:bs]
+            # Q5 cache key: identity + version of the two input tensors.  The tensors themselves are HELD while the key
+            # is live, so the caching allocator cannot hand their addresses to different data of the same shape (a second
+            # object denoised right after the first would otherwise hit the first object's K/V).
             key = (source_image_latents.data_ptr(), source_image_latents._version, tuple(source_image_latents.shape),
-                   encoder_hidden_states.data_ptr(), encoder_hidden_states._version, B)
-            if self.cache_reference and self._ref_key == key:
+                   encoder_hidden_states.data_ptr(), encoder_hidden_states._version, tuple(encoder_hidden_states.shape), B)
+            if (self.cache_reference and self._ref_key == key
+                    and eng.reference_cache_valid(B, x.shape[2], x.shape[3], text.shape[1], bs)):
                 img = dict(reuse_ref=True)
             else:
                 img = dict(source_latents=self._f32(source_image_latents, dev), encoder_text=enc_text.contiguous())
                 self._ref_key = key
+                self._ref_hold = (source_image_latents, encoder_hidden_states) if self.cache_reference else None
         out = eng.forward(x, t, text, **cam, **img)
         if cam:
-            self.current_camera_embedding = eng.camera_embedding(B)
+            self.current_camera_embedding = eng.camera_embedding(cam["target_camera"].shape[0])
         hidden_states = out.to(out_dtype)
         if not return_dict:
             return hidden_states
@@ -301,13 +325,13 @@ def create_mvd_pipeline(pretrained_model_name_or_path: str, dtype: torch.dtype =
                         use_camera_conditioning: bool = True, use_image_conditioning: bool = True,
                         img_ref_scale: float = 0.25, cam_modulation_strength: float = 1.0, cam_output_dim: int = 1024,
                         cam_hidden_dim: int = 512, simple_cam_encoder: bool = False, cache_dir=None,
-                        scheduler_config: Optional[Dict[str, Any]] = None):
-    """mvd_unet.py:388-453.  Needs diffusers + a local SD-2.1 snapshot for the VAE / text encoder /
-    scheduler (the callers either side of the hot path -- SURVEY.md 8f rows N1-N3)."""
-    try:
-        from .pipeline import build_pipeline
-    except ImportError as e:  # pragma: no cover
-        raise L.MvdError(f"create_mvd_pipeline needs diffusers (not installed in this image): {e}")
+                        scheduler_config: Optional[Dict[str, Any]] = None, *, unet_config: Optional[UNetConfig] = None,
+                        init: str = "default"):
+    """mvd_unet.py:388-453: returns an ``MVDPipeline`` whose ``unet`` is this ``MultiViewUNet`` and whose scheduler is the
+    interpolated SNR-shifted DDPM scheduler (``scheduler_config`` is accepted and ignored like the reference, :401,
+    420-421).  Text encoder / VAE are attached when a local snapshot directory provides them; nothing is downloaded.
+    ``unet_config`` / ``init`` are keyword-only extensions for checkpoint-free construction (tests, synthetic weights)."""
+    from .pipeline import build_pipeline
     return build_pipeline(pretrained_model_name_or_path, dtype, use_camera_conditioning, use_image_conditioning,
                           img_ref_scale, cam_modulation_strength, cam_output_dim, cam_hidden_dim, simple_cam_encoder,
-                          cache_dir)
+                          cache_dir, unet_config=unet_config, init=init)

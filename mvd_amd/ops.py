@@ -157,3 +157,21 @@ def nchw_to_nhwc(x, scale=None, shift=None):
     y = torch.empty(B, H, W, c, device=x.device, dtype=torch.bfloat16)
     L.call("mvd_op_nchw_to_nhwc", _p(x), B, c, H * W, _p(scale), _p(shift), _p(y), _s())
     return y
+
+
+def last_gemm_plan():
+    """dict(cfg, splitk, tiles, grid, per_cu) of this thread's last GEMM / conv launch."""
+    out = (C.c_int * 5)()
+    L.call("mvd_debug_last_gemm_plan", out)
+    return dict(cfg=out[0], splitk=out[1], tiles=out[2], grid=out[3], per_cu=out[4])
+
+
+def last_attention_plan():
+    out = (C.c_int * 2)()
+    L.call("mvd_debug_last_attention_plan", out)
+    return dict(waves=out[0], workgroups=out[1])
+
+
+def engine_splitk(m, n, k, geglu=False):
+    """The split-K factor the engine's schedule uses for this GEMM / conv size."""
+    return L.lib().mvd_debug_pick_splitk(m, n, k, int(geglu))

@@ -12,6 +12,7 @@ from types import SimpleNamespace
 
 import torch.nn as nn
 
+from .attention import AttnProcessor2_0HIP
 from .config import UNetConfig
 
 
@@ -19,12 +20,6 @@ class _NoForward(nn.Module):
     def forward(self, *a, **k):  # pragma: no cover
         raise RuntimeError(f"{type(self).__name__} is a parameter container; the forward runs in the MVD HIP engine")
 
-
-class AttnProcessorPlaceholder:
-    """Stands for diffusers' AttnProcessor2_0 (the 'original_processor' the adapter wraps)."""
-
-    def __call__(self, *a, **k):  # pragma: no cover
-        raise RuntimeError("the block's own attention is computed inside the MVD HIP engine")
 
 
 class Attention(_NoForward):
@@ -36,7 +31,7 @@ class Attention(_NoForward):
         self.to_k = nn.Linear(cross_dim, inner, bias=False)
         self.to_v = nn.Linear(cross_dim, inner, bias=False)
         self.to_out = nn.ModuleList([nn.Linear(inner, query_dim), nn.Dropout(0.0)])
-        self.processor = AttnProcessorPlaceholder()
+        self.processor = AttnProcessor2_0HIP()     # diffusers' default processor, on the HIP kernels
 
 
 class GEGLU(_NoForward):

@@ -89,3 +89,27 @@ def g2_cameras(B: int = 3) -> tuple:
 
 def g2_mod_input(variant: str, name: str, dim: int, B: int) -> torch.Tensor:
     return fx(f"cam.{variant}.x.{name}", (B, dim, 2, 3))
+
+
+# ---- G6: synthetic images for load_image (utils.py:36-49): name -> (height, width, PIL mode, target_size)
+G6_CASES = {
+    "rgba_64x48_to_32": (64, 48, "RGBA", (32, 32)),
+    "rgb_40x40_to_64x48": (40, 40, "RGB", (64, 48)),
+}
+
+
+def g6_image(name: str):
+    """Smooth-ish seeded uint8 image (random low-res grid upsampled + noise) so LANCZOS has structure to filter."""
+    import numpy as np
+    h, w, mode, _ = G6_CASES[name]
+    c = len(mode)
+    rng = np.random.RandomState(zlib_seed("g6." + name))
+    coarse = rng.randint(0, 256, size=(h // 8 + 1, w // 8 + 1, c)).astype(np.float32)
+    img = np.kron(coarse, np.ones((8, 8, 1), np.float32))[:h, :w]
+    img = np.clip(img + rng.randint(-20, 21, size=img.shape), 0, 255)
+    return img.astype(np.uint8)
+
+
+def zlib_seed(name: str) -> int:
+    import zlib
+    return zlib.crc32(name.encode()) & 0x7FFFFFFF

@@ -6,6 +6,7 @@ import time
 
 import torch
 
+from mvd_amd.utils import look_at  # noqa: F401  (synthetic cameras: product-side helper, re-exported for the tests)
 from oracle import mvd as OM
 from oracle import sd21_unet as OU
 
@@ -16,21 +17,6 @@ def rel_l2(got: torch.Tensor, want: torch.Tensor) -> float:
 
 def max_rel(got: torch.Tensor, want: torch.Tensor) -> float:
     return ((got.float().cpu() - want.float()).abs().max() / want.float().abs().max().clamp_min(1e-12)).item()
-
-
-def look_at(azim_deg: float, elev_deg: float = 20.0, radius: float = 2.0) -> torch.Tensor:
-    """4x4 camera-to-world look-at pose on a sphere (SURVEY.md 8d synthetic cameras)."""
-    import math
-    a, e = math.radians(azim_deg), math.radians(elev_deg)
-    pos = torch.tensor([radius * math.cos(e) * math.sin(a), radius * math.sin(e), radius * math.cos(e) * math.cos(a)])
-    fwd = -pos / pos.norm()
-    up = torch.tensor([0.0, 1.0, 0.0])
-    right = torch.linalg.cross(fwd, up)
-    right = right / right.norm()
-    nup = torch.linalg.cross(right, fwd)
-    m = torch.eye(4)
-    m[:3, 0], m[:3, 1], m[:3, 2], m[:3, 3] = right, nup, -fwd, pos
-    return m
 
 
 def make_inputs(cfg: OU.UNetConfig, batch: int, hw, text_len: int, seed: int = 0, cam_dim: int = 1024):

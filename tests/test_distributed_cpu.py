@@ -35,6 +35,71 @@ def _worker(rank, world, port, ret):
     torch.distributed.destroy_process_group()
 
 
+class _FakeEngine:
+    """CPU stand-in with the two attributes/one method of MVDEngine the broadcast path uses."""
+
+    def __init__(self, weights):
+        self._weights = weights
+        self._arenas = {}
+
+    def consolidate_weights(self):
+        if self._arenas:
+            return
+        flat = {f"{i}/{k}": t for i, d in enumerate(self._weights) for k, t in d.items()}
+        self._arenas, views = D.pack_into_arenas(flat)
+        for name, v in views.items():
+            i, k = name.split("/", 1)
+            self._weights[int(i)][k] = v
+
+
+def _engine_weights(rank):
+    g = torch.Generator().manual_seed(11)
+    ref = [{"a.w": torch.randn(300, 64, generator=g).to(torch.bfloat16), "a.b": torch.randn(300, generator=g),
+            "conv.w": torch.randn(77, 9, generator=g).to(torch.bfloat16)},
+           {"enc.w": torch.randn(1000, generator=g).to(torch.bfloat16), "enc.g": torch.randn(5, generator=g)}]
+    mine = [{k: (v.clone() if rank == 0 else torch.zeros_like(v)) for k, v in d.items()} for d in ref]
+    return ref, mine
+
+
+def _engine_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    D.init_from_env("gloo")
+    ref, mine = _engine_weights(rank)
+    eng = _FakeEngine(mine)
+    stats = D.broadcast_engine_weights(eng, 0, bucket_bytes=4096)        # several slices per arena
+    ok = all(torch.equal(eng._weights[i][k], v) for i, d in enumerate(ref) for k, v in d.items())
+    # every slot is an aligned VIEW of its dtype's arena: the broadcast touched no staging copy
+    for d in eng._weights:
+        for t in d.values():
+            a = eng._arenas[t.dtype]
+            lo = a.data_ptr()
+            ok = ok and lo <= t.data_ptr() < lo + a.numel() * a.element_size() and (t.data_ptr() - lo) % D.ARENA_ALIGN == 0
+    arena_bytes = sum(a.numel() * a.element_size() for a in eng._arenas.values())
+    ok = ok and stats["bytes"] == arena_bytes and stats["buckets"] >= 3 and stats["seconds"] >= 0.0
+    D.barrier()
+    ret[rank] = ok
+    torch.distributed.destroy_process_group()
+
+
+def test_gloo_engine_weight_broadcast_world2():
+    """The engine-weight path of bench.py (``broadcast_engine_weights``) on two CPU-side fake engines."""
+    world, port = 2, _free_port()
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_engine_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+def test_pack_into_arenas_layout():
+    ref, _ = _engine_weights(0)
+    flat = {f"{i}/{k}": t for i, d in enumerate(ref) for k, t in d.items()}
+    arenas, views = D.pack_into_arenas(flat)
+    assert set(arenas) == {torch.bfloat16, torch.float32} and set(views) == set(flat)
+    for k, v in views.items():
+        assert torch.equal(v, flat[k]) and v.shape == flat[k].shape
+        assert (v.data_ptr() - arenas[v.dtype].data_ptr()) % D.ARENA_ALIGN == 0
+
+
 def test_gloo_weight_broadcast_world2():
     world, port = 2, _free_port()
     ret = mp.get_context("spawn").Manager().dict()

@@ -33,8 +33,15 @@ def main(fetch_dir, write_dir, out):
         res[cls] = {"launches": n, "fetch_bytes_per_launch": 2.0 * fk * 1024 / n, "write_bytes_per_launch": wk * 1024 / max(nw, 1),
                     "hbm_bytes_per_launch": 2.0 * fk * 1024 / n + wk * 1024 / max(nw, 1),
                     "note": "FETCH_SIZE x2 (gfx950 128-B requests tallied at 64 B) + WRITE_SIZE, KB -> bytes"}
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_source_sha
+    res["_meta"] = {"kernel_src_sha": kernel_source_sha(), "workload": "cfg4 cold",
+                    "note": "bench.py quotes roofline.traffic from this file only while the kernel sources hash to kernel_src_sha"}
     json.dump(res, open(out, "w"), indent=1)
     for k, v in res.items():
+        if k.startswith("_"):
+            continue
         print(f"{k:22s} launches={v['launches']:5d} fetch={v['fetch_bytes_per_launch']/1e6:9.1f} MB write={v['write_bytes_per_launch']/1e6:9.1f} MB")
 
 if __name__ == "__main__":
