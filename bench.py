@@ -124,7 +124,10 @@ def output_check(model, batch, kw, step):
     the full-batch forward equal a batch-2 forward of the same rows -- computed by different tile configurations and
     grids -- to bf16 accumulation-order noise."""
     keep = model.fourier_projection
-    model.fourier_projection = model.camera_encoder.draw_projection(batch["sample"].device) if model.camera_encoder is not None else None
+    if model.camera_encoder is not None:      # a fixed projection for the screen (the timed steps draw a fresh one per call, Q1)
+        g = torch.Generator().manual_seed(4321)
+        enc_dim = 6 * model.camera_encoder.pos_enc_dim
+        model.fourier_projection = (torch.randn(model.camera_encoder.output_dim, enc_dim, generator=g) / math.sqrt(enc_dim)).to(batch["sample"].device)
     a, b = step().clone(), step().clone()
     res = {"deterministic": bool(torch.equal(a, b))}
     assert res["deterministic"], "two forwards of the same inputs differ"
@@ -135,7 +138,9 @@ def output_check(model, batch, kw, step):
             small = model(batch["sample"][:2], batch["t"][:2], batch["text"][:2], **{k: v[:2] for k, v in cam.items()}).sample
         rel = ((full - small).norm() / small.norm()).item()
         res["full_batch_vs_batch2_rel_l2"] = round(rel, 6)
-        assert rel <= 1.5e-2, f"full-batch rows differ from their batch-2 recomputation: rel-L2 {rel}"
+        # two bf16 evaluations of ~300 chained ops each sit ~1e-2 from the fp32 truth (tests/test_cfg4_shapes_gpu.py); a wrong
+        # tile or a race shows up as O(1)
+        assert rel <= 3e-2, f"full-batch rows differ from their batch-2 recomputation: rel-L2 {rel}"
     model.fourier_projection = keep
     return res
 

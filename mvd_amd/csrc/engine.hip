@@ -600,7 +600,7 @@ int forward_impl(mvd_engine* e, const mvd_forward_args_t& a, hipStream_t s, bool
   if (use_cam && a.cam_batch > 0 && (a.cam_batch > a.batch || a.batch % a.cam_batch)) { mvd_set_error("forward: camera batch %d must divide the sample batch %d", a.cam_batch, a.batch); return -1; }
   // the input FiLM uses the 4-wide "output" modulator (mvd_unet.py:74-80, 256-258): any other in_channels is a broadcast
   // error in the reference and would read past the [B][4] scale/shift rows here -- reject before any launch
-  if (use_cam && cfg.in_channels != 4) { mvd_set_error("forward: camera conditioning needs in_channels == 4 (the 'output' modulator is 4 wide), got %d", cfg.in_channels); return -1; }
+  if (!dry && use_cam && cfg.in_channels != 4) { mvd_set_error("forward: camera conditioning needs in_channels == 4 (the 'output' modulator is 4 wide), got %d", cfg.in_channels); return -1; }
 
   e->tmp.dry = e->act.dry = dry;
   e->tmp.off = e->tmp.high = 0;

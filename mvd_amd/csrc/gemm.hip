@@ -21,6 +21,8 @@
 #include <string.h>
 #include "kernels.h"
 
+thread_local MvdLaunchPlan g_mvd_last_gemm = {-1, 1, 0, 0, 0};
+
 namespace {
 
 template <int BM_, int BN_, int WM_, int WN_>
@@ -491,8 +493,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const MvdGemmArgs a)
 
 struct CfgInfo { int bm, bn, tn_even; };
 
-thread_local MvdLaunchPlan g_mvd_last_gemm = {-1, 1, 0, 0, 0};
-
 template <class C, int AMODE, bool GLDS, bool SPLITK, bool DBG>
 int launch_mode3(const MvdGemmArgs& a, hipStream_t s) {
   static int per_cu = 0;   // resident workgroups per CU for this instantiation (LDS- and VGPR-limited)
@@ -653,6 +653,9 @@ int mvd_launch_gemm(const MvdGemmArgs& a, hipStream_t s, int force_cfg) {
     return mvd_launch_gemm_ring(a, s);
   }
 #endif
+  // force_cfg 16 / 17 = the lock-step (round-1) form of tile configs 6 / 7; 6 / 7 and the heuristic take the ping-pong kernels
+  bool legacy = MVD_ENV_INT("MVD_GEMM_LEGACY", 0) != 0;
+  if (cfg == 16 || cfg == 17) { legacy = true; cfg -= 10; }
   if (cfg == 14) { glds = true; cfg = 8; }       // force_cfg 14 = the 128x320 tile (LDS-DMA only)
   else if (cfg >= 8 && cfg < 14) { glds = true; cfg -= 8; } else if (cfg >= 0 && cfg < 6) { glds = false; }
   if (cfg < 0) cfg = mvd_gemm_pick_config(a);
@@ -666,8 +669,10 @@ int mvd_launch_gemm(const MvdGemmArgs& a, hipStream_t s, int force_cfg) {
     case 4: return launch_cfg<C4>(a, s, glds);
     case 6:
       if (!a.geglu || a.seg[0].mode != MVD_A_DENSE || a.splitk > 1) { mvd_set_error("gemm: tile config 6 is GEGLU-only"); return -1; }
+      if (!legacy && !a.dbg && mvd_gemm_pp_applicable(a)) return mvd_launch_gemm_pp(a, s);
       return launch_mode2<C6, 0, true, false>(a, s);
     case 7:
+      if (!legacy && !a.dbg && !a.geglu && mvd_gemm_pp_applicable(a)) return mvd_launch_gemm_pp(a, s);
 #ifdef MVD_PROBE
       if (use_ring && !a.out_f32 && !a.dbg) return mvd_launch_gemm_ring(a, s);
 #endif

@@ -1,0 +1,474 @@
+// 256x320-tile bf16 MFMA GEMM / implicit-GEMM 3x3 convolution for gfx950, "ping-pong" form.
+//
+//   out[M][N] = alpha * ( A[M][K] . W[N][K]^T + bias[N] + rowvec[batch(m)][N] ) + res[M][N]
+//
+// Same contract, operand layouts, LDS image and epilogues as gemm.hip (see its header); what differs is how one
+// workgroup spends its time.  gemm.hip's 256x320 kernel ran its eight waves in lock step: every wave computed the
+// 64-bit global addresses of its nine LDS-DMA loads (~130 vector instructions per 64-deep K slab, several of them
+// quarter-rate integer multiplies), then all waves multiplied, then all met at one barrier -- the matrix pipe sat
+// idle through every address-and-read phase (55 % busy, profiles/r01_pmc_sq_counters_attention_gemm.txt).  Here:
+//
+// * BUFFER-ADDRESSED LDS-DMA (buffer_load_dwordx4 ... lds): the per-lane byte offset of a load is loop invariant
+//   (row-in-block * row pitch + 16-byte chunk) and everything that changes from slab to slab / row block to row
+//   block / tile to tile is a SCALAR offset.  A dense slab costs no vector instruction at all; a convolution tap
+//   costs a bounds compare and a select per load (out-of-image taps get an offset beyond num_records, for which
+//   the hardware returns zeros -- no zero buffer, no 64-bit address arithmetic).
+// * TWO WAVE GROUPS ONE PHASE APART: waves 0-3 and waves 4-7 (the two waves of each SIMD) run the same program,
+//   but the second group executes one extra s_barrier up front.  A slab is four phases, each closed by a barrier:
+//       R0: ds_read the fragments of k 0..31 into registers, issue the LDS-DMA of the NEXT slab
+//       M0: 40 MFMAs out of registers (s_setprio 1)
+//       R1: ds_read the fragments of k 32..63, wait for this wave's own DMAs
+//       M1: 40 MFMAs
+//   so at any time one wave of a SIMD is in an MFMA-only phase while its partner reads LDS / issues loads / runs
+//   an epilogue: the matrix pipe always has a wave to serve.  DMAs stay in flight across barriers (raw s_barrier,
+//   explicit counted waits); a tile's epilogue runs under the partner group's MFMA phase.
+//
+// Hazard bookkeeping (g = barrier generation; group 0 passes its p-th program barrier at g = p, group 1 at p + 1;
+// slab t occupies program barriers 4t .. 4t+3):
+//   WAR  stage (t+1)&1 is re-filled by DMAs issued in R0(t): group 0 in (4t-1, 4t], group 1 in (4t, 4t+1].  Its last
+//        readers are the R1(t-1) phases, closed (with lgkmcnt(0)) by barriers 4t-2 / 4t-1.
+//   RAW  slab t+1 is first read by group 0 in R0(t+1), after barrier 4t+3.  Group 0 waits for its DMAs before barrier
+//        4t+2 (end of its R1(t)), group 1 before barrier 4t+3 (end of its R1(t)).
+#include <stdlib.h>
+#include <string.h>
+#include "kernels.h"
+
+namespace {
+
+constexpr int BM = 256, BN = 320, NT = 512;
+constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES, LDS_BYTES = 2 * STAGE_BYTES;
+constexpr int A_IT = BM * 8 / NT, B_IT = BN * 8 / NT;   // 4, 5 DMA instructions per wave per slab
+constexpr unsigned OOB = 0x80000000u;                   // voffset of a load that must return zeros (>= num_records)
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+MVD_DEVINL int swz_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// one 16-byte-per-lane LDS-DMA: LDS destination = wave-uniform base + lane * 16
+MVD_DEVINL void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_wave_base, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
+}
+
+// WM x WN wave grid: 2 x 4 (wave tile 128 x 80) for plain epilogues, 4 x 2 (64 x 160: value/gate column tiles pair
+// up inside a wave) for GEGLU.  AMODE: 0 dense, 1 conv, 2 conv + dense (1x1 shortcut) segment, 3 conv behind a fused
+// nearest-2x upsample.
+template <int WM, int WN, int AMODE, bool SPLITK>
+__global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
+  constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 16, TN = WTN / 16;
+  constexpr bool GEGLU = WM == 4;
+  constexpr bool HAS_CONV = AMODE != 0;
+  constexpr bool UPS = AMODE == 3;
+  static_assert((WTM * 128) % 2048 == 0 && (WTN % 16) == 0, "fragment rows of a wave share one swizzle pattern");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: LDS-DMA bases and the group test stay on the SALU
+  const int grp = wave >> 2;                                      // ping-pong group (SIMD partners are waves w, w + 4)
+  const int wm = wave / WN, wn = wave % WN;
+  const int ntn = a.N / BN;
+  const int ntm = (a.M + BM - 1) / BM;
+  const int lrow = tid >> 3;                                      // 0..63: row inside a 64-row DMA block
+  const int kc = (tid & 7) ^ ((lrow >> 1) & 7);                   // source chunk (the XOR swizzle lives on the source side)
+
+  // ---- tile walk (as gemm.hip): XCD x owns a contiguous range of work items, its workgroups stride through it
+  const int S = SPLITK ? a.splitk : 1;
+  const int ntiles = ntn * ntm * S;
+  const int xcd = blockIdx.x & 7, xj = blockIdx.x >> 3;
+  const int gx = (gridDim.x >> 3) + ((int)(gridDim.x & 7) > xcd ? 1 : 0);
+  const int tq = ntiles >> 3, tr = ntiles & 7;
+  const int tstart = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+  const int tend = tstart + tq + (xcd < tr ? 1 : 0);
+  int tile = tstart + xj;
+  if (tile >= tend) return;
+
+  const MvdASeg& cs = a.seg[0];                       // conv segment (AMODE 1, 2)
+  const MvdASeg& ds = a.seg[AMODE == 2 ? 1 : 0];      // dense segment (AMODE 0, 2)
+  const int nkt_conv = HAS_CONV ? (9 * cs.c0) / 64 : 0;
+  const int nkt = a.Ktot / 64;
+  const int conv_c2 = cs.c0 * 2;                      // bytes per input pixel
+  const int conv_rowB = cs.inW * conv_c2;             // bytes per input row
+  constexpr bool conv_ups = UPS;
+  const int limH = conv_ups ? 2 * cs.inH : cs.inH, limW = conv_ups ? 2 * cs.inW : cs.inW;
+  const int dc0 = ds.c0, dc1 = ds.c1;
+
+  // ---- buffer descriptors (scalar).  The conv descriptor starts one row + one pixel BEFORE the feature map so
+  // that tap (dy, dx) is a non-negative scalar offset (dy * row + dx * pixel) from a per-lane base; nothing below
+  // the map is ever dereferenced (those taps are out of the image and take the OOB offset).
+  __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.W), 0, (int)((size_t)a.N * a.ldw * 2), 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_c = rs_w, rs_d0 = rs_w, rs_d1 = rs_w;
+  if (HAS_CONV) {
+    const int shift = conv_rowB + conv_c2;
+    const size_t bytes = (size_t)(a.M / a.rows_per_batch) * cs.inH * cs.inW * conv_c2;
+    rs_c = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(const_cast<bf16_t*>(cs.p0)) - shift, 0, (int)(bytes + shift), 0x00020000);
+  }
+  if (AMODE == 0 || AMODE == 2) {
+    rs_d0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(ds.p0), 0, (int)((size_t)a.M * dc0 * 2), 0x00020000);
+    if (dc1) rs_d1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(ds.p1), 0, (int)((size_t)a.M * dc1 * 2), 0x00020000);
+  }
+  // loop-invariant per-lane offsets: row-in-block * pitch + chunk.  Rows >= M of a dense source lie beyond num_records
+  // and read as zeros (their outputs are never stored).
+  const unsigned voff_w = (unsigned)lrow * (unsigned)a.ldw * 2u + kc * 16;
+  const unsigned voff_d0 = (unsigned)lrow * (unsigned)dc0 * 2u + kc * 16;
+  const unsigned voff_d1 = (unsigned)lrow * (unsigned)dc1 * 2u + kc * 16;
+
+  // ---- loader state of the tile whose slabs are being fetched (may run one tile ahead of the multiplying tile)
+  int ld_m0 = 0, ld_n0 = 0;
+  unsigned a_base[A_IT];      // conv: byte offset of the window's top-left tap (shifted origin), + chunk
+  int a_yx[A_IT];             // conv: (oy*stride) | (ox*stride) << 16
+  auto setup_loader = [&](int work) {
+    const int t = S == 1 ? work : work / S;
+    ld_m0 = (t / ntn) * BM;
+    ld_n0 = (t % ntn) * BN;
+    if (HAS_CONV) {
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        int m = ld_m0 + lrow + i * 64;
+        m = m < a.M ? m : a.M - 1;
+        const int b = m / a.rows_per_batch;
+        const int rem = m - b * a.rows_per_batch;
+        const int oy = rem / a.outW, ox = rem - oy * a.outW;
+        const int ys = oy * cs.stride, xs = ox * cs.stride;
+        a_yx[i] = ys | (xs << 16);
+        // top-left tap (ys-1, xs-1) in source coordinates; with the fused nearest-2x upsample the source row of
+        // upsampled row r is r >> 1 (arithmetic), the parity-dependent +1 of the middle tap is added per load
+        const int ty = conv_ups ? ((ys - 1) >> 1) : ys - 1, tx = conv_ups ? ((xs - 1) >> 1) : xs - 1;
+        a_base[i] = (unsigned)((b * cs.inH * cs.inW + (ty + 1) * cs.inW + (tx + 1)) * conv_c2 + kc * 16);
+      }
+    }
+  };
+
+  // issue the LDS-DMAs of slab lk (of the loader's tile) into stage st
+  auto issue_loads = [&](int st, int lk) {
+    unsigned char* sa = smem + st * STAGE_BYTES + wave * 1024;
+    unsigned char* sb = sa + A_BYTES;
+    if (HAS_CONV && (AMODE != 2 || lk < nkt_conv)) {
+      // K order [channel slice][tap][64 channels] (gemm.hip): slice = lk / 9, tap = lk % 9
+      const int sl = lk / 9, tap = lk - sl * 9;
+      const int dy = tap / 3, dx = tap - dy * 3;
+      unsigned soff = (unsigned)(sl * 128);
+      if (!conv_ups) soff += (unsigned)(dy * conv_rowB + dx * conv_c2);
+      else soff += (unsigned)((dy == 2 ? conv_rowB : 0) + (dx == 2 ? conv_c2 : 0));
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        const int iy = (a_yx[i] & 0xffff) - 1 + dy, ix = (a_yx[i] >> 16) - 1 + dx;
+        const bool ok = (unsigned)iy < (unsigned)limH && (unsigned)ix < (unsigned)limW;
+        unsigned vo = a_base[i];
+        if (conv_ups) {   // middle tap: +1 source row/pixel iff the upsampled coordinate (ys-1 / xs-1) is odd, i.e. ys / xs even
+          if (dy == 1) vo += (a_yx[i] & 1) ? 0u : (unsigned)conv_rowB;
+          if (dx == 1) vo += (a_yx[i] & 0x10000) ? 0u : (unsigned)conv_c2;
+        }
+        dma16(rs_c, sa + i * 8192, ok ? vo : OOB, soff);
+      }
+    } else {
+      const int cc = (lk - nkt_conv) << 6;             // first K column of the slab inside the dense segment
+      const bool first = cc < dc0;
+      const int pitch = (first ? dc0 : dc1) * 2;
+      const unsigned col2 = (unsigned)((first ? cc : cc - dc0) * 2);
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        const unsigned soff = (unsigned)(ld_m0 + i * 64) * (unsigned)pitch + col2;
+        if (first) dma16(rs_d0, sa + i * 8192, voff_d0, soff);
+        else dma16(rs_d1, sa + i * 8192, voff_d1, soff);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i)
+      dma16(rs_w, sb + i * 8192, voff_w, (unsigned)(ld_n0 + i * 64) * (unsigned)a.ldw * 2u + (unsigned)lk * 128u);
+  };
+
+  f32x4 acc[TM][TN];
+  const int fr = lane & 15, fq = lane >> 4;
+  const float alpha = a.alpha;
+
+  // accumulators start at bias + per-batch row vector (as gemm.hip)
+  auto init_acc = [&](int m0, int n0) {
+    asm volatile("" : "+s"(m0), "+s"(n0));
+    const int nb = n0 + wn * WTN + fq * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (SPLITK) return;
+    if (a.bias) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + nb + j * 16);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][j] = bv;
+      }
+    }
+    if (GEGLU || !a.rowvec) return;
+    if (a.rows_per_batch % BM == 0) {        // the whole tile lies in one batch element: one vector for all rows
+      const float* rv = a.rowvec + (size_t)(m0 / a.rows_per_batch) * a.ld_rowvec + nb;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const f32x4 r = *reinterpret_cast<const f32x4*>(rv + j * 16);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][j] += r;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        int m = m0 + wm * WTM + i * 16 + fr;
+        m = m < a.M ? m : a.M - 1;
+        const float* rv = a.rowvec + (size_t)(m / a.rows_per_batch) * a.ld_rowvec + nb;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] += *reinterpret_cast<const f32x4*>(rv + j * 16);
+      }
+    }
+  };
+
+  // ---- epilogue.  Every load / store is BUFFER addressed: the per-lane byte offset (row fr of a 16-row tile, column
+  // group) is tile invariant, the tile / row-tile / column-tile position is a scalar offset, and rows >= M fall beyond
+  // num_records (loads return zeros, stores are dropped) -- no address arithmetic, no per-row predication.
+  // A lane owns 4 consecutive channels (8 bytes) of one row per 16-column tile; v_permlane16_swap pairs up two adjacent
+  // column tiles so that a lane holds 8 consecutive channels: one 16-byte access per lane, 64 contiguous bytes per row
+  // and instruction, half the memory instructions (the store tail is issue bound, not bandwidth bound).
+  //   before: lane (fr, fq) has tile j cols 4fq..4fq+3 in `x`, tile j+1 cols 4fq..4fq+3 in `y`
+  //   after : fq 0: tile j cols 0-7 | fq 1: tile j+1 cols 0-7 | fq 2: tile j cols 8-15 | fq 3: tile j+1 cols 8-15  (x | y)
+  auto swap_pair = [&](u32x2& x, u32x2& y) {
+    auto r0 = __builtin_amdgcn_permlane16_swap(x[0], y[0], false, false);
+    auto r1 = __builtin_amdgcn_permlane16_swap(x[1], y[1], false, false);
+    x[0] = r0[0]; y[0] = r0[1]; x[1] = r1[0]; y[1] = r1[1];
+  };
+  const int pair_col = (fq & 1) * 16 + (fq >> 1) * 8;      // column of the lane's 16-byte piece inside a pair of column tiles
+  auto epilogue = [&](int m0, int n0, int ks) {
+    asm volatile("" : "+s"(m0), "+s"(n0));
+    const int row0 = m0 + wm * WTM;                        // (scalar) first row of the wave tile
+    if (SPLITK) {   // raw fp32 partial tile; bias / residual are applied by the reduce kernel
+      __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(a.part + (size_t)ks * a.M * a.N, 0, (int)((size_t)a.M * a.N * 4), 0x00020000);
+      const int vo = (fr * a.N + fq * 4) * 4;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs_p, vo,
+                                                 ((row0 + i * 16) * a.N + n0 + wn * WTN + j * 16) * 4, 0);
+      return;
+    }
+    __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)((size_t)a.M * a.ldo * 2), 0x00020000);
+    const int vo16 = (fr * a.ldo + pair_col) * 2, vo8 = (fr * a.ldo + fq * 4) * 2;
+    if constexpr (GEGLU) {
+      // column tiles (j, j+1) = (value, gate) of ONE 16-wide output tile; output tiles are then paired for 16-byte stores
+      constexpr int NO = TN / 2;                           // output column tiles per wave
+      const int oc0 = (n0 + wn * WTN) / 2;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        u32x2 o[NO];
+#pragma unroll
+        for (int q = 0; q < NO; ++q) {
+          const f32x4 v = acc[i][2 * q], g = acc[i][2 * q + 1];    // bias already in
+          o[q] = u32x2{pack2bf(v[0] * gelu_erf_f(g[0]), v[1] * gelu_erf_f(g[1])), pack2bf(v[2] * gelu_erf_f(g[2]), v[3] * gelu_erf_f(g[3]))};
+        }
+        const int so = ((row0 + i * 16) * a.ldo + oc0) * 2;
+#pragma unroll
+        for (int q = 0; q + 1 < NO; q += 2) {
+          swap_pair(o[q], o[q + 1]);
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{o[q][0], o[q][1], o[q + 1][0], o[q + 1][1]}, rs_o, vo16, so + q * 32, 0);
+        }
+        if (NO & 1) __builtin_amdgcn_raw_buffer_store_b64(o[NO - 1], rs_o, vo8, so + (NO - 1) * 32, 0);
+      }
+    } else {
+      const bool has_res = a.res != nullptr;
+      __amdgpu_buffer_rsrc_t rs_r = rs_o;
+      if (has_res) rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.res), 0, (int)((size_t)a.M * a.ldres * 2), 0x00020000);
+      const int vr16 = (fr * a.ldres + pair_col) * 2, vr8 = (fr * a.ldres + fq * 4) * 2;
+      constexpr int NP = TN / 2;                           // column-tile pairs (+ one single tile when TN is odd)
+      // residual rows are fetched for RG row tiles at a time (one memory round trip per batch, not per row tile)
+      constexpr int RG = HAS_CONV ? 2 : 4;
+#pragma unroll
+      for (int i0 = 0; i0 < TM; i0 += RG) {
+        u32x4 rp[RG][NP > 0 ? NP : 1];
+        u32x2 rs1[RG];
+        if (has_res) {
+#pragma unroll
+          for (int g = 0; g < RG; ++g) {
+            const int so = ((row0 + (i0 + g) * 16) * a.ldres + n0 + wn * WTN) * 2;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) rp[g][q] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, vr16, so + q * 64, 0);
+            if (TN & 1) rs1[g] = __builtin_amdgcn_raw_buffer_load_b64(rs_r, vr8, so + (TN - 1) * 32, 0);
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < RG; ++g) {
+          const int i = i0 + g;
+          const int so = ((row0 + i * 16) * a.ldo + n0 + wn * WTN) * 2;
+          auto finish = [&](f32x4 v, u32x2 r) -> u32x2 {
+            v *= alpha;
+            if (has_res) { v[0] += bflo(r[0]); v[1] += bfhi(r[0]); v[2] += bflo(r[1]); v[3] += bfhi(r[1]); }
+            return u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+          };
+#pragma unroll
+          for (int q = 0; q < NP; ++q) {
+            u32x2 ra = {0u, 0u}, rb = {0u, 0u};
+            if (has_res) {   // the 16-byte residual piece is in the paired layout: the same swap (an involution) un-pairs it
+              ra = u32x2{rp[g][q][0], rp[g][q][1]}; rb = u32x2{rp[g][q][2], rp[g][q][3]};
+              swap_pair(ra, rb);
+            }
+            u32x2 oa = finish(acc[i][2 * q], ra), ob = finish(acc[i][2 * q + 1], rb);
+            swap_pair(oa, ob);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{oa[0], oa[1], ob[0], ob[1]}, rs_o, vo16, so + q * 64, 0);
+          }
+          if (TN & 1) __builtin_amdgcn_raw_buffer_store_b64(finish(acc[i][TN - 1], has_res ? rs1[g] : u32x2{0u, 0u}), rs_o, vo8, so + (TN - 1) * 32, 0);
+        }
+      }
+    }
+  };
+
+  auto slab_range = [&](int work, int& k0, int& k1) {
+    if (S == 1) { k0 = 0; k1 = nkt; return; }
+    const int ks = work % S;
+    k0 = (ks * nkt) / S;
+    k1 = ((ks + 1) * nkt) / S;
+  };
+
+  // fragment registers of ONE 32-deep half slab; read in an R phase, consumed by the M phase behind the barrier
+  // Every fragment row of a wave is fr + a multiple of 16, so the XOR swizzle ((row >> 1) & 7) is that of fr: ONE per-lane
+  // byte offset per half slab (the halves differ by chunk bit 2 = 64 bytes), the row tile is an immediate offset and the
+  // stage / wave position is scalar.
+  bf16x8 af[TM], wf[TN];
+  const int frag_off = fr * 128 + ((fq ^ ((fr >> 1) & 7)) << 4);
+  auto read_frags = [&](int st, int half) {
+    const unsigned char* sa = smem + st * STAGE_BYTES + wm * (WTM * 128) + (frag_off ^ (half * 64));
+    const unsigned char* sb = smem + st * STAGE_BYTES + A_BYTES + wn * (WTN * 128) + (frag_off ^ (half * 64));
+#pragma unroll
+    for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sb + j * 2048);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + i * 2048);
+  };
+  auto mfma_half = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // phase boundary: nothing moves across it at compile time; the barrier itself is the raw s_barrier (no implied
+  // vmcnt(0): LDS-DMAs stay in flight across it)
+  auto phase_end = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- prologue: first slab of the first work item, by all waves together
+  int kt0, kt1;
+  slab_range(tile, kt0, kt1);
+  setup_loader(tile);
+  issue_loads(0, kt0);
+  {
+    const int tl0 = S == 1 ? tile : tile / S;
+    init_acc((tl0 / ntn) * BM, (tl0 % ntn) * BN);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  phase_end();
+  if (grp == 1) phase_end();             // the stagger: group 1 runs one phase behind group 0 from here on
+
+  int cur = 0;
+  for (;;) {
+    const int tl = S == 1 ? tile : tile / S;
+    const int ks = S == 1 ? 0 : tile - tl * S;
+    const int m0 = (tl / ntn) * BM, n0 = (tl % ntn) * BN;
+    const int next_tile = tile + gx;
+    const bool have_next = next_tile < tend;
+    int nkt0 = 0, nkt1 = 0;
+    if (have_next) slab_range(next_tile, nkt0, nkt1);
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const bool last_k = kt + 1 == kt1;
+      const bool more = !last_k || have_next;
+      // ---- R0
+      read_frags(cur, 0);
+      if (more) {
+        if (last_k) setup_loader(next_tile);           // the loader runs ahead into the next work item
+        issue_loads(cur ^ 1, last_k ? nkt0 : kt + 1);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      phase_end();
+      // ---- M0
+      mfma_half();
+      phase_end();
+      // ---- R1
+      read_frags(cur, 1);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's DMAs of the next slab have landed
+      phase_end();
+      // ---- M1
+      mfma_half();
+      phase_end();
+      if (last_k) {            // under the partner group's MFMA phase
+        epilogue(m0, n0, ks);
+        if (have_next) {
+          const int tn = S == 1 ? next_tile : next_tile / S;
+          init_acc((tn / ntn) * BM, (tn % ntn) * BN);
+        }
+      }
+      cur ^= 1;
+    }
+    if (!have_next) break;
+    tile = next_tile; kt0 = nkt0; kt1 = nkt1;
+  }
+  if (grp == 0) phase_end();             // balance the extra barrier group 1 executed up front
+}
+
+template <int WM, int WN, int AMODE, bool SPLITK>
+int launch_pp(const MvdGemmArgs& a, hipStream_t s) {
+  static bool init = false;
+  if (!init) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<WM, WN, AMODE, SPLITK>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) { mvd_set_error("gemm_pp: hipFuncSetAttribute: %s", hipGetErrorString(e)); return -2; }
+    init = true;
+  }
+  const int ntm = (a.M + BM - 1) / BM, ntn = a.N / BN;
+  int grid = 256;                                         // one 144 KB workgroup per CU
+  const int ntiles = ntm * ntn * (a.splitk > 1 ? a.splitk : 1);
+  if (ntiles < grid) grid = ((ntiles + 7) / 8) * 8;
+  g_mvd_last_gemm.tiles = ntiles; g_mvd_last_gemm.grid = grid; g_mvd_last_gemm.per_cu = 1;
+  hipLaunchKernelGGL((gemm_pp_kernel<WM, WN, AMODE, SPLITK>), dim3(grid), dim3(NT), LDS_BYTES, s, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { mvd_set_error("gemm_pp launch: %s", hipGetErrorString(e)); return -3; }
+  return 0;
+}
+
+template <int WM, int WN>
+int launch_pp_mode(const MvdGemmArgs& a, hipStream_t s) {
+  const bool sk = a.splitk > 1;
+  if (a.seg[0].mode == MVD_A_DENSE) return sk ? launch_pp<WM, WN, 0, true>(a, s) : launch_pp<WM, WN, 0, false>(a, s);
+  if (a.seg[0].ups) {
+    if (a.nseg != 1) { mvd_set_error("gemm_pp: an upsampling convolution takes no shortcut segment"); return -1; }
+    return sk ? launch_pp<WM, WN, 3, true>(a, s) : launch_pp<WM, WN, 3, false>(a, s);
+  }
+  if (a.nseg == 1) return sk ? launch_pp<WM, WN, 1, true>(a, s) : launch_pp<WM, WN, 1, false>(a, s);
+  return sk ? launch_pp<WM, WN, 2, true>(a, s) : launch_pp<WM, WN, 2, false>(a, s);
+}
+
+}  // namespace
+
+// Every byte offset the kernel forms must fit the 32-bit buffer addressing (and stay below OOB = 2^31).
+bool mvd_gemm_pp_applicable(const MvdGemmArgs& a) {
+  const size_t lim = (size_t)1 << 31;
+  if (a.N % BN || a.Ktot % 64 || a.out_f32) return false;      // (fp32 outputs exist at M = batch only: gemm.hip)
+  if ((size_t)a.N * a.ldw * 2 >= lim) return false;
+  if ((size_t)(a.M + BM) * a.ldo * 2 >= lim || (a.res && (size_t)(a.M + BM) * a.ldres * 2 >= lim)) return false;
+  if (a.splitk > 1 && (size_t)(a.M + BM) * a.N * 4 >= lim) return false;
+  for (int i = 0; i < a.nseg; ++i) {
+    const MvdASeg& g = a.seg[i];
+    if (g.mode == MVD_A_DENSE) {
+      if ((size_t)(a.M + BM) * (g.c0 > g.c1 ? g.c0 : g.c1) * 2 >= lim) return false;
+    } else {
+      const size_t bytes = (size_t)(a.M / a.rows_per_batch) * g.inH * g.inW * g.c0 * 2 + (size_t)(g.inW + 1) * g.c0 * 2;
+      if (bytes + (size_t)3 * g.inW * g.c0 * 2 >= lim) return false;
+      if (2 * g.inH >= 32768 || 2 * g.inW >= 32768) return false;     // (y, x) packed in 16 bits each
+    }
+  }
+  return true;
+}
+
+// geglu selects the 4 x 2 wave grid (arguments already validated by mvd_launch_gemm)
+int mvd_launch_gemm_pp(const MvdGemmArgs& a, hipStream_t s) {
+  if (a.geglu) {
+    if (a.seg[0].mode != MVD_A_DENSE || a.splitk > 1) { mvd_set_error("gemm_pp: GEGLU needs a dense, unsplit problem"); return -1; }
+    return launch_pp<4, 2, 0, false>(a, s);
+  }
+  return launch_pp_mode<2, 4>(a, s);
+}

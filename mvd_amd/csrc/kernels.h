@@ -47,6 +47,11 @@ struct MvdGemmArgs {
 int mvd_launch_gemm(const MvdGemmArgs& a, hipStream_t s, int force_cfg = -1);
 // what the calling thread's last mvd_launch_gemm launched (tests assert that the persistent multi-tile path ran)
 struct MvdLaunchPlan { int cfg, splitk, tiles, grid, per_cu; };
+extern thread_local MvdLaunchPlan g_mvd_last_gemm;
+// 256x320 "ping-pong" kernels (gemm_pp.hip): buffer-addressed LDS-DMA, two wave groups one phase apart.  Used for tile
+// configs 6 (GEGLU) and 7 whenever every byte offset fits 32-bit buffer addressing; arguments validated by mvd_launch_gemm.
+bool mvd_gemm_pp_applicable(const MvdGemmArgs& a);
+int mvd_launch_gemm_pp(const MvdGemmArgs& a, hipStream_t s);
 // ring-pipelined 256x320 experiment (gemm_ring.hip, linked into probe builds only); arguments already validated by mvd_launch_gemm
 int mvd_launch_gemm_ring(const MvdGemmArgs& a, hipStream_t s);
 // sum the split-K partials and apply the GEMM epilogue (bias, row vector, alpha, residual) -> out

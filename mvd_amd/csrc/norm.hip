@@ -38,8 +38,12 @@ __global__ void gn_stats_kernel(const bf16_t* __restrict__ x0, const bf16_t* __r
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; sft[j] = 0.f; }
     int n = 0;
-    if (row0 + r < row1) unpack8(*reinterpret_cast<const u32x4*>(src + (size_t)(row0 + r) * ld), sft);
-    for (int row = row0 + r; row < row1; row += R) {
+    int row = row0 + r;
+    if (row < row1) {   // the thread's first sample is the shift (its own deviation is 0): no extra memory round trip
+      unpack8(*reinterpret_cast<const u32x4*>(src + (size_t)row * ld), sft);
+      n = 1; row += R;
+    }
+    for (; row < row1; row += R) {
       float f[8];
       unpack8(*reinterpret_cast<const u32x4*>(src + (size_t)row * ld), f);
 #pragma unroll
