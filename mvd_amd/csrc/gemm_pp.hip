@@ -15,10 +15,10 @@
 //   the hardware returns zeros -- no zero buffer, no 64-bit address arithmetic).
 // * TWO WAVE GROUPS ONE PHASE APART: waves 0-3 and waves 4-7 (the two waves of each SIMD) run the same program,
 //   but the second group executes one extra s_barrier up front.  A slab is four phases, each closed by a barrier:
-//       R0: ds_read the fragments of k 0..31 into registers, issue the LDS-DMA of the NEXT slab
+//       R0: ds_read the fragments of k 0..31 into registers, issue LDS-DMAs of the NEXT slab
 //       M0: 40 MFMAs out of registers (s_setprio 1)
-//       R1: ds_read the fragments of k 32..63, wait for this wave's own DMAs
-//       M1: 40 MFMAs
+//       R1: ds_read the fragments of k 32..63 (group 0: the rest of the next slab's W loads; group 1: wait for its loads)
+//       M1: 40 MFMAs (group 0: then wait for its loads)
 //   so at any time one wave of a SIMD is in an MFMA-only phase while its partner reads LDS / issues loads / runs
 //   an epilogue: the matrix pipe always has a wave to serve.  DMAs stay in flight across barriers (raw s_barrier,
 //   explicit counted waits); a tile's epilogue runs under the partner group's MFMA phase.
@@ -27,17 +27,17 @@
 // slab t occupies program barriers 4t .. 4t+3):
 //   WAR  stage (t+1)&1 is re-filled by DMAs issued in R0(t): group 0 in (4t-1, 4t], group 1 in (4t, 4t+1].  Its last
 //        readers are the R1(t-1) phases, closed (with lgkmcnt(0)) by barriers 4t-2 / 4t-1.
+//        (group 0 also issues in its R1(t), (4t+1, 4t+2]: later still.)
 //   RAW  slab t+1 is first read by group 0 in R0(t+1), after barrier 4t+3.  Group 0 waits for its DMAs before barrier
-//        4t+2 (end of its R1(t)), group 1 before barrier 4t+3 (end of its R1(t)).
+//        4t+3 (end of its M1(t)), group 1 before barrier 4t+3 (end of its R1(t)).
 #include <stdlib.h>
 #include <string.h>
 #include "kernels.h"
 
 namespace {
 
-constexpr int BM = 256, BN = 320, NT = 512;
-constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES, LDS_BYTES = 2 * STAGE_BYTES;
-constexpr int A_IT = BM * 8 / NT, B_IT = BN * 8 / NT;   // 4, 5 DMA instructions per wave per slab
+constexpr int BN = 320, NT = 512;
+constexpr int B_BYTES = BN * 128, B_IT = BN * 8 / NT;   // 5 W-side DMA instructions per wave-slice per slab
 constexpr unsigned OOB = 0x80000000u;                   // voffset of a load that must return zeros (>= num_records)
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -52,8 +52,11 @@ MVD_DEVINL void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_wave_base,
 // WM x WN wave grid: 2 x 4 (wave tile 128 x 80) for plain epilogues, 4 x 2 (64 x 160: value/gate column tiles pair
 // up inside a wave) for GEGLU.  AMODE: 0 dense, 1 conv, 2 conv + dense (1x1 shortcut) segment, 3 conv behind a fused
 // nearest-2x upsample.
-template <int WM, int WN, int AMODE, bool SPLITK>
+// BM = 256 rows per tile (the default) or 128 (levels whose 256-row grid cannot fill the chip: twice the tiles, wave tile 64 x 80).
+template <int BM, int WM, int WN, int AMODE, bool SPLITK>
 __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
+  constexpr int A_BYTES = BM * 128, STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int A_IT = BM * 8 / NT;                       // A-side DMA instructions per wave per slab (4 / 2)
   constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 16, TN = WTN / 16;
   constexpr bool GEGLU = WM == 4;
   constexpr bool HAS_CONV = AMODE != 0;
@@ -136,10 +139,14 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
     }
   };
 
-  // issue the LDS-DMAs of slab lk (of the loader's tile) into stage st
-  auto issue_loads = [&](int st, int lk) {
+  // LDS-DMAs of slab lk (of the loader's tile) into stage st.  The A operand is loaded by all eight waves (each its own
+  // 8-row slice of every 64-row block: the convolution's per-lane window state belongs to that slice); the W operand -- whose
+  // offsets are scalar apart from one invariant per-lane term -- is loaded by GROUP 0 ALONE (both slices w and w+4 of each
+  // block), spread over its two read phases.  Per slab group 0 issues 4 + 3 loads in R0 and 7 in R1, group 1 its 4 A loads in
+  // R0: no phase carries more than 7 of the 72 loads of a slab (evenly split, R0 carried 9 per wave and was the long pole
+  // against the partner's 640-cycle MFMA phase).
+  auto issue_a = [&](int st, int lk) {
     unsigned char* sa = smem + st * STAGE_BYTES + wave * 1024;
-    unsigned char* sb = sa + A_BYTES;
     if (HAS_CONV && (AMODE != 2 || lk < nkt_conv)) {
       // K order [channel slice][tap][64 channels] (gemm.hip): slice = lk / 9, tap = lk % 9
       const int sl = lk / 9, tap = lk - sl * 9;
@@ -170,9 +177,16 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
         else dma16(rs_d1, sa + i * 8192, voff_d1, soff);
       }
     }
+  };
+  // W loads q0 <= q < q1 of group 0's ten per slab: q -> (64-row block q >> 1, 8-row slice wave + 4 * (q & 1))
+  constexpr int W_Q = 2 * B_IT, W_Q_R0 = 3;
+  auto issue_w = [&](int st, int lk, int q0, int q1) {
+    unsigned char* sb = smem + st * STAGE_BYTES + A_BYTES + wave * 1024;
+    const unsigned ldw2 = (unsigned)a.ldw * 2u;
+    const unsigned so = (unsigned)ld_n0 * ldw2 + (unsigned)lk * 128u;
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i)
-      dma16(rs_w, sb + i * 8192, voff_w, (unsigned)(ld_n0 + i * 64) * (unsigned)a.ldw * 2u + (unsigned)lk * 128u);
+    for (int q = 0; q < W_Q; ++q)
+      if (q >= q0 && q < q1) dma16(rs_w, sb + (q >> 1) * 8192 + (q & 1) * 4096, voff_w, so + (unsigned)((q >> 1) * 64 + (q & 1) * 32) * ldw2);
   };
 
   f32x4 acc[TM][TN];
@@ -356,7 +370,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
   int kt0, kt1;
   slab_range(tile, kt0, kt1);
   setup_loader(tile);
-  issue_loads(0, kt0);
+  issue_a(0, kt0);
+  if (grp == 0) issue_w(0, kt0, 0, W_Q);
   {
     const int tl0 = S == 1 ? tile : tile / S;
     init_acc((tl0 / ntn) * BM, (tl0 % ntn) * BN);
@@ -377,11 +392,13 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
     for (int kt = kt0; kt < kt1; ++kt) {
       const bool last_k = kt + 1 == kt1;
       const bool more = !last_k || have_next;
+      const int nlk = last_k ? nkt0 : kt + 1;          // the slab being fetched
       // ---- R0
       read_frags(cur, 0);
       if (more) {
         if (last_k) setup_loader(next_tile);           // the loader runs ahead into the next work item
-        issue_loads(cur ^ 1, last_k ? nkt0 : kt + 1);
+        issue_a(cur ^ 1, nlk);
+        if (grp == 0) issue_w(cur ^ 1, nlk, 0, W_Q_R0);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       phase_end();
@@ -390,10 +407,16 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
       phase_end();
       // ---- R1
       read_frags(cur, 1);
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's DMAs of the next slab have landed
+      if (grp == 0) {
+        if (more) issue_w(cur ^ 1, nlk, W_Q_R0, W_Q);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // group 1's loads of the next slab (issued in its R0) have landed
+      }
       phase_end();
       // ---- M1
       mfma_half();
+      if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // group 0's loads (R0 + R1) have landed: one MFMA phase of cover
       phase_end();
       if (last_k) {            // under the partner group's MFMA phase
         epilogue(m0, n0, ks);
@@ -410,42 +433,44 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
   if (grp == 0) phase_end();             // balance the extra barrier group 1 executed up front
 }
 
-template <int WM, int WN, int AMODE, bool SPLITK>
+template <int BM, int WM, int WN, int AMODE, bool SPLITK>
 int launch_pp(const MvdGemmArgs& a, hipStream_t s) {
+  constexpr int LDS_BYTES = 2 * (BM * 128 + B_BYTES);
   static bool init = false;
   if (!init) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<WM, WN, AMODE, SPLITK>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<BM, WM, WN, AMODE, SPLITK>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) { mvd_set_error("gemm_pp: hipFuncSetAttribute: %s", hipGetErrorString(e)); return -2; }
     init = true;
   }
   const int ntm = (a.M + BM - 1) / BM, ntn = a.N / BN;
-  int grid = 256;                                         // one 144 KB workgroup per CU
+  int grid = 256;                                         // one 144 KB (112 KB at BM = 128) workgroup per CU
   const int ntiles = ntm * ntn * (a.splitk > 1 ? a.splitk : 1);
   if (ntiles < grid) grid = ((ntiles + 7) / 8) * 8;
   g_mvd_last_gemm.tiles = ntiles; g_mvd_last_gemm.grid = grid; g_mvd_last_gemm.per_cu = 1;
-  hipLaunchKernelGGL((gemm_pp_kernel<WM, WN, AMODE, SPLITK>), dim3(grid), dim3(NT), LDS_BYTES, s, a);
+  hipLaunchKernelGGL((gemm_pp_kernel<BM, WM, WN, AMODE, SPLITK>), dim3(grid), dim3(NT), LDS_BYTES, s, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { mvd_set_error("gemm_pp launch: %s", hipGetErrorString(e)); return -3; }
   return 0;
 }
 
-template <int WM, int WN>
+template <int BM, int WM, int WN>
 int launch_pp_mode(const MvdGemmArgs& a, hipStream_t s) {
   const bool sk = a.splitk > 1;
-  if (a.seg[0].mode == MVD_A_DENSE) return sk ? launch_pp<WM, WN, 0, true>(a, s) : launch_pp<WM, WN, 0, false>(a, s);
+  if (a.seg[0].mode == MVD_A_DENSE) return sk ? launch_pp<BM, WM, WN, 0, true>(a, s) : launch_pp<BM, WM, WN, 0, false>(a, s);
   if (a.seg[0].ups) {
     if (a.nseg != 1) { mvd_set_error("gemm_pp: an upsampling convolution takes no shortcut segment"); return -1; }
-    return sk ? launch_pp<WM, WN, 3, true>(a, s) : launch_pp<WM, WN, 3, false>(a, s);
+    return sk ? launch_pp<BM, WM, WN, 3, true>(a, s) : launch_pp<BM, WM, WN, 3, false>(a, s);
   }
-  if (a.nseg == 1) return sk ? launch_pp<WM, WN, 1, true>(a, s) : launch_pp<WM, WN, 1, false>(a, s);
-  return sk ? launch_pp<WM, WN, 2, true>(a, s) : launch_pp<WM, WN, 2, false>(a, s);
+  if (a.nseg == 1) return sk ? launch_pp<BM, WM, WN, 1, true>(a, s) : launch_pp<BM, WM, WN, 1, false>(a, s);
+  return sk ? launch_pp<BM, WM, WN, 2, true>(a, s) : launch_pp<BM, WM, WN, 2, false>(a, s);
 }
 
 }  // namespace
 
 // Every byte offset the kernel forms must fit the 32-bit buffer addressing (and stay below OOB = 2^31).
 bool mvd_gemm_pp_applicable(const MvdGemmArgs& a) {
+  constexpr int BM = 256;
   const size_t lim = (size_t)1 << 31;
   if (a.N % BN || a.Ktot % 64 || a.out_f32) return false;      // (fp32 outputs exist at M = batch only: gemm.hip)
   if ((size_t)a.N * a.ldw * 2 >= lim) return false;
@@ -464,11 +489,13 @@ bool mvd_gemm_pp_applicable(const MvdGemmArgs& a) {
   return true;
 }
 
-// geglu selects the 4 x 2 wave grid (arguments already validated by mvd_launch_gemm)
+// geglu selects the 4 x 2 wave grid (arguments already validated by mvd_launch_gemm).
+// (A 128-row instantiation of the same kernel -- BM = 128, wave tile 64 x 80, for the 16x16 / 8x8 levels -- was measured
+//  against the 128x160 lock-step tiles those levels use: no faster, profiles/r02_probe_pp128.log; not instantiated.)
 int mvd_launch_gemm_pp(const MvdGemmArgs& a, hipStream_t s) {
   if (a.geglu) {
     if (a.seg[0].mode != MVD_A_DENSE || a.splitk > 1) { mvd_set_error("gemm_pp: GEGLU needs a dense, unsplit problem"); return -1; }
-    return launch_pp<4, 2, 0, false>(a, s);
+    return launch_pp<256, 4, 2, 0, false>(a, s);
   }
-  return launch_pp_mode<2, 4>(a, s);
+  return launch_pp_mode<256, 2, 4>(a, s);
 }
