@@ -132,8 +132,9 @@ int mvd_op_linear(const void* a, const void* a2, int k1, int k2, const void* w, 
                   int ld_rowvec, int rows_per_batch, const void* res, float alpha, int geglu, void* out, int out_f32,
                   int m, int n, int force_cfg, int splitk, float* splitk_ws /* splitk*m*n floats when splitk > 1 */,
                   void* stream);
-/* 3x3 conv (pad 1) on NHWC bf16 as implicit GEMM; optional fused 1x1 shortcut on (sc, sc2) */
-int mvd_op_conv3x3(const void* x, int batch, int in_h, int in_w, int cin, int stride, int upsample, const void* w,
+/* 3x3 conv (pad 1) on NHWC bf16 as implicit GEMM; optional fused 1x1 shortcut on (sc, sc2).  asym_pad = 1 (stride 2 only):
+ * zero padding on the bottom/right edge only -- diffusers' VAE Downsample2D(padding=0). */
+int mvd_op_conv3x3(const void* x, int batch, int in_h, int in_w, int cin, int stride, int upsample, int asym_pad, const void* w,
                    const float* bias, const float* rowvec, int ld_rowvec, const void* res, const void* sc, const void* sc2,
                    int sc_c1, int sc_c2, void* out, int cout, int force_cfg, int splitk, float* splitk_ws, void* stream);
 /* softmax(scale * q.k^T).v per head of 64 channels.  scale == 0 selects the engine's form: q is already multiplied
@@ -170,6 +171,33 @@ int mvd_op_ddpm_step(const float* model_out, const float* sample, const float* n
                      float c3, float sigma, float* out, int64_t n, void* stream);
 /* classifier-free guidance combine of [uncond | cond] stacked on the batch dim (pipeline.py:156-158) */
 int mvd_op_cfg_combine(const float* uncond_cond, float guidance_scale, float* out, int64_t n_half, void* stream);
+
+/* ---- AutoencoderKL (SD-2.1 VAE) either side of the loop ------------------------------------ */
+/* Replaces: vae.encode(x).latent_dist (pipeline.py:115) and vae.decode(z).sample (pipeline.py:171-176) of diffusers'
+ * AutoencoderKL.  Slot names / layouts: DESIGN.md "VAE weight slots" (mvd_amd/vae.py packs a diffusers state dict). */
+typedef struct {
+  int in_channels;                         /* 3 */
+  int latent_channels;                     /* 4 */
+  int num_levels;                          /* 4 */
+  int block_out_channels[MVD_MAX_LEVELS];  /* 128 256 512 512 */
+  int layers_per_block;                    /* 2 */
+  int norm_num_groups;                     /* 32 */
+  float norm_eps;                          /* 1e-6 */
+} mvd_vae_config_t;
+typedef struct mvd_vae mvd_vae_t;
+int mvd_vae_create(const mvd_vae_config_t* cfg, mvd_vae_t** out);
+int mvd_vae_destroy(mvd_vae_t* v);
+int mvd_vae_set_weight(mvd_vae_t* v, const char* slot, const void* ptr, int64_t numel, int dtype);
+/* bytes for one encode (decode = 0: height/width of the IMAGE) or decode (decode = 1: height/width of the LATENT) */
+int64_t mvd_vae_workspace_bytes(mvd_vae_t* v, int batch, int height, int width, int decode);
+int mvd_vae_bind_workspace(mvd_vae_t* v, void* ws, int64_t ws_bytes);
+/* image [batch][in_channels][H][W] fp32 in [-1,1] -> moments [batch][2*latent][H/f][W/f] fp32 = (mean | logvar) */
+int mvd_vae_encode(mvd_vae_t* v, const float* image_nchw, int batch, int height, int width, float* moments, void* stream);
+/* latents [batch][latent][h][w] fp32 (already divided by the scaling factor) -> image [batch][in_channels][f*h][f*w] fp32 */
+int mvd_vae_decode(mvd_vae_t* v, const float* latents_nchw, int batch, int height, int width, float* image, void* stream);
+/* DiagonalGaussianDistribution.sample(): out = (mean + exp(0.5*clamp(logvar,-30,20)) * noise) * scale; noise/out [batch][c][hw] */
+int mvd_op_gaussian_sample(const float* moments, const float* noise, int batch, int channels, int hw, float scale, float* out,
+                           void* stream);
 
 #ifdef __cplusplus
 }

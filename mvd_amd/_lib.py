@@ -29,6 +29,14 @@ class mvd_config_t(C.Structure):
     ]
 
 
+class mvd_vae_config_t(C.Structure):
+    _fields_ = [
+        ("in_channels", C.c_int), ("latent_channels", C.c_int), ("num_levels", C.c_int),
+        ("block_out_channels", C.c_int * MVD_MAX_LEVELS), ("layers_per_block", C.c_int), ("norm_num_groups", C.c_int),
+        ("norm_eps", C.c_float),
+    ]
+
+
 class mvd_forward_args_t(C.Structure):
     _fields_ = [
         ("batch", C.c_int), ("height", C.c_int), ("width", C.c_int), ("text_len", C.c_int),
@@ -63,7 +71,7 @@ _SIGS = {
     "mvd_op_linear": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                 C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_void_p, C.c_void_p]),
-    "mvd_op_conv3x3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+    "mvd_op_conv3x3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                  C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mvd_op_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -85,6 +93,14 @@ _SIGS = {
     "mvd_op_ddpm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float,
                                    C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
     "mvd_op_cfg_combine": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
+    "mvd_vae_create": (C.c_int, [C.POINTER(mvd_vae_config_t), C.POINTER(C.c_void_p)]),
+    "mvd_vae_destroy": (C.c_int, [C.c_void_p]),
+    "mvd_vae_set_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_int]),
+    "mvd_vae_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mvd_vae_bind_workspace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "mvd_vae_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "mvd_vae_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "mvd_op_gaussian_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS)

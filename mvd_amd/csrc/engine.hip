@@ -920,14 +920,14 @@ int mvd_op_linear(const void* a, const void* a2, int k1, int k2, const void* w, 
   return mvd_launch_gemm(g, (hipStream_t)stream, force_cfg);
 }
 
-int mvd_op_conv3x3(const void* x, int batch, int in_h, int in_w, int cin, int stride, int upsample, const void* w,
+int mvd_op_conv3x3(const void* x, int batch, int in_h, int in_w, int cin, int stride, int upsample, int asym_pad, const void* w,
                    const float* bias, const float* rowvec, int ld_rowvec, const void* res, const void* sc, const void* sc2,
                    int sc_c1, int sc_c2, void* out, int cout, int force_cfg, int splitk, float* splitk_ws, void* stream) {
   MvdGemmArgs g; memset(&g, 0, sizeof(g));
   const int oh = upsample ? in_h * 2 : (stride == 2 ? (in_h + 1) / 2 : in_h);
   const int ow = upsample ? in_w * 2 : (stride == 2 ? (in_w + 1) / 2 : in_w);
   g.seg[0].p0 = (const bf16_t*)x; g.seg[0].c0 = cin; g.seg[0].mode = MVD_A_CONV3; g.seg[0].ksize = 9 * cin;
-  g.seg[0].inH = in_h; g.seg[0].inW = in_w; g.seg[0].stride = stride; g.seg[0].ups = upsample;
+  g.seg[0].inH = in_h; g.seg[0].inW = in_w; g.seg[0].stride = stride; g.seg[0].ups = upsample; g.seg[0].asym = asym_pad;
   g.nseg = 1; g.Ktot = 9 * cin;
   if (sc) {
     g.seg[1].p0 = (const bf16_t*)sc; g.seg[1].p1 = (const bf16_t*)sc2; g.seg[1].c0 = sc_c1; g.seg[1].c1 = sc_c2;

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(C::NT, C::MIN_WAVES) void gemm_kernel(const MvdGemm
         const int rem = m - b * a.rows_per_batch;
         const int oy = rem / a.outW, ox = rem - oy * a.outW;
         a_pb[i] = b * cs.inH * cs.inW;
-        a_yx[i] = (oy * cs.stride) | ((ox * cs.stride) << 16);
+        a_yx[i] = (oy * cs.stride + cs.asym) | ((ox * cs.stride + cs.asym) << 16);   // asym: the window starts AT (2oy, 2ox)
       }
     }
   };
@@ -620,6 +620,7 @@ int mvd_launch_gemm(const MvdGemmArgs& a, hipStream_t s, int force_cfg) {
       if (g.c0 % 64 || g.c1 % 64 || g.ksize != g.c0 + g.c1 || !g.p0 || (g.c1 && !g.p1)) { mvd_set_error("gemm: bad dense segment %d (c0=%d c1=%d ksize=%d)", i, g.c0, g.c1, g.ksize); return -1; }
     } else if (g.mode == MVD_A_CONV3) {
       if (g.c0 % 64 || g.c1 != 0 || g.ksize != 9 * g.c0 || !g.p0 || (g.stride != 1 && g.stride != 2) || (g.ups && g.stride != 1)) { mvd_set_error("gemm: bad conv segment %d", i); return -1; }
+      if (g.asym && (g.asym != 1 || g.stride != 2 || (g.inH & 1) || (g.inW & 1))) { mvd_set_error("gemm: bottom/right-only padding needs stride 2 and an even input size"); return -1; }
       const int eh = g.ups ? 2 * g.inH : (g.stride == 2 ? (g.inH + 1) / 2 : g.inH);
       const int ew = g.ups ? 2 * g.inW : (g.stride == 2 ? (g.inW + 1) / 2 : g.inW);
       if (eh != a.outH || ew != a.outW || a.rows_per_batch != a.outH * a.outW || a.M % a.rows_per_batch) { mvd_set_error("gemm: conv geometry mismatch (in %dx%d out %dx%d rpb %d M %d)", g.inH, g.inW, a.outH, a.outW, a.rows_per_batch, a.M); return -1; }

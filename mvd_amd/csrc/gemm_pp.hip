@@ -129,7 +129,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
         const int b = m / a.rows_per_batch;
         const int rem = m - b * a.rows_per_batch;
         const int oy = rem / a.outW, ox = rem - oy * a.outW;
-        const int ys = oy * cs.stride, xs = ox * cs.stride;
+        const int ys = oy * cs.stride + cs.asym, xs = ox * cs.stride + cs.asym;   // asym: the window starts AT (2oy, 2ox)
         a_yx[i] = ys | (xs << 16);
         // top-left tap (ys-1, xs-1) in source coordinates; with the fused nearest-2x upsample the source row of
         // upsampled row r is r >> 1 (arithmetic), the parity-dependent +1 of the middle tap is added per load

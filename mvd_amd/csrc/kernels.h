@@ -19,6 +19,8 @@ struct MvdASeg {          // one K segment of the A operand
   int inH, inW;           // conv: stored input spatial size
   int stride;             // conv: 1 or 2
   int ups;                // conv: 1 = nearest 2x upsample fused in front of the conv
+  int asym;               // conv, stride 2 only: 1 = zero padding on the bottom/right edge only (diffusers' VAE
+                          // Downsample2D(padding=0): F.pad(x, (0,1,0,1)) then a pad-0 conv), 0 = the usual pad 1 all round
 };
 
 struct MvdGemmArgs {

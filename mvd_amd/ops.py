@@ -48,8 +48,9 @@ def linear(a, w, bias=None, a2=None, rowvec=None, rows_per_batch=0, res=None, al
 
 
 def conv3x3(x, w_packed, bias=None, stride=1, upsample=False, rowvec=None, res=None, shortcut=None,
-            shortcut2=None, force_cfg=-1, splitk=1):
-    """x: (B,H,W,Cin) bf16; w_packed: (Cout, 9*Cin [+ Csc]) bf16 tap-major."""
+            shortcut2=None, force_cfg=-1, splitk=1, asym_pad=False):
+    """x: (B,H,W,Cin) bf16; w_packed: (Cout, 9*Cin [+ Csc]) bf16 tap-major.  asym_pad (stride 2): zero padding on the
+    bottom/right edge only (the VAE's Downsample2D(padding=0))."""
     _bf16(x, w_packed, res, shortcut, shortcut2)
     B, H, W, Cin = x.shape
     cout = w_packed.shape[0]
@@ -59,7 +60,7 @@ def conv3x3(x, w_packed, bias=None, stride=1, upsample=False, rowvec=None, res=N
     c1 = shortcut.shape[-1] if shortcut is not None else 0
     c2 = shortcut2.shape[-1] if shortcut2 is not None else 0
     ws = torch.empty(splitk * B * oh * ow * cout, device=x.device, dtype=torch.float32) if splitk > 1 else None
-    L.call("mvd_op_conv3x3", _p(x), B, H, W, Cin, stride, int(upsample), _p(w_packed), _p(bias), _p(rowvec),
+    L.call("mvd_op_conv3x3", _p(x), B, H, W, Cin, stride, int(upsample), int(asym_pad), _p(w_packed), _p(bias), _p(rowvec),
            rowvec.shape[1] if rowvec is not None else 0, _p(res), _p(shortcut), _p(shortcut2), c1, c2, _p(out), cout,
            force_cfg, splitk, _p(ws), _s())
     return out
