@@ -510,6 +510,238 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_pipe_kernel(const MvdAttnArgs
   }
 }
 
+#ifdef MVD_PROBE
+// ------------------------------------------------------------------------------------------------------------------
+// "Ping-pong" attention (prescaled Q, 64-key tiles): 8 waves x 32 queries per workgroup, one workgroup per CU, the two
+// waves of every SIMD (waves w and w + 4) ONE PHASE APART, as in gemm_pp.hip.  A wave's key tile t is two phases, each
+// closed by a raw s_barrier:
+//     A_t (matrix):  O^T += V(t-1)^T . P(t-1)^T  (12 MFMAs incl. the row-sum tile)  and  S(t)^T = K(t) . Q^T  (8 MFMAs)
+//     B_t (vector):  online softmax of S(t) -> bf16 P(t) in registers  (max, deferred rescale, 32 v_exp, 16 v_cvt_pk)
+// so while one wave of a SIMD feeds the matrix pipe its partner runs the exponentials -- the overlap the free-running
+// 3-waves-per-SIMD kernel above only gets statistically (its SQ counters: matrix pipe 54 % busy, vector issue 67 %).
+// The matrix phase runs OUT OF REGISTERS: the K(t+1) and V(t) fragments it needs are read from LDS during the vector
+// phase B_t (whose LDS port is otherwise idle), so A is 20 back-to-back MFMAs.
+// K/V tiles arrive by buffer-addressed LDS-DMA (wave w loads the w-th 8-key piece of each tile: no VGPR round trip, no
+// ds_write; keys >= nk lie beyond num_records and read as zeros) into THREE-stage rings: at the END of B_t a wave issues
+// K(t+3) and V(t+2) and waits for them at the end of its B_{t+1} -- two whole phases of cover.
+// (g = barrier generation: group 0 leaves A_t at 2t, B_t at 2t+1; group 1 one later.  WAR: stage of K(t+3) = stage of
+//  K(t), last read in B_{t-1}, which both groups have left by g = 2t, before either issues (end of B_t).  V(t+2) likewise
+//  replaces V(t-1).  RAW: K(t+3) / V(t+2) are first read by group 0 in B_{t+2}, behind g = 2t+4; group 0's wait sits
+//  before g = 2t+3, group 1's before 2t+4.)
+__global__ __launch_bounds__(512, 2) void attn_pp_kernel(const MvdAttnArgs a) {
+  constexpr int QB = 256, KV_TILE = 64, TILE_BYTES = KV_TILE * 128, NSTG = 3;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * NSTG * TILE_BYTES];   // K ring | V ring
+  typedef __attribute__((address_space(3))) void lds_void;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;
+  const int lq = lane & 31, lh = lane >> 5;
+  const int head = blockIdx.y;
+  int bz = blockIdx.z;
+  const int pi = bz / a.batch;
+  bz -= pi * a.batch;
+  const MvdAttnProblem& P = a.p[pi];
+  const int nq = P.nq, nk = P.nk;
+  const int qblk0 = blockIdx.x * QB;
+  if (qblk0 >= nq) return;  // whole workgroup exits together (uniform)
+
+  const bf16_t* qp = P.q + (size_t)bz * P.bsq + head * 64;
+  bf16_t* op = P.o + (size_t)bz * P.bso + head * 64;
+  const int qrow = qblk0 + wave * 32 + lq;
+  const int qrow_c = qrow < nq ? qrow : nq - 1;
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+    qf[ks] = *reinterpret_cast<const bf16x8*>(qp + (size_t)qrow_c * P.ldq + ks * 16 + lh * 8);
+
+  // ---- K/V loader: buffer descriptors over this batch element's rows; per-lane offset = key-in-piece row + head + chunk
+  // (the XOR swizzles of k_off / v_off live on the SOURCE side: the DMA writes lane-linear)
+  const int ldk2 = P.ldk * 2, ldv2 = P.ldv * 2;
+  __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(P.k + (size_t)bz * P.bsk), 0, (int)((size_t)nk * ldk2), 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(P.v + (size_t)bz * P.bsv), 0, (int)((size_t)nk * ldv2), 0x00020000);
+  const int ld_key = wave * 8 + (lane >> 3);                          // key row inside the tile this lane fetches
+  const unsigned vo_k = (unsigned)ld_key * (unsigned)ldk2 + head * 128 + (((lane & 7) ^ ((ld_key >> 1) & 7)) << 4);
+  const unsigned vo_v = (unsigned)ld_key * (unsigned)ldv2 + head * 128 + (((lane & 7) ^ (((ld_key >> 1) & 1) << 2)) << 4);
+  const int nkb = (nk + KV_TILE - 1) / KV_TILE;
+  auto load_k = [&](int t) {   // K tile t -> K ring stage t % 3
+    if (t < nkb) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lds_void*)(smem + (t % NSTG) * TILE_BYTES + wave * 1024), 16, (int)vo_k,
+                                                          t * KV_TILE * ldk2, 0, 0);
+  };
+  auto load_v = [&](int t) {
+    if (t < nkb) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lds_void*)(smem + (NSTG + t % NSTG) * TILE_BYTES + wave * 1024), 16, (int)vo_v,
+                                                          t * KV_TILE * ldv2, 0, 0);
+  };
+
+  f32x16 o0 = {}, o1 = {}, ol = {};
+  bf16x8 ones_frag;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones_frag[j] = (lq == 0) ? (__bf16)1.0f : (__bf16)0.0f;
+  float m_run = 0.f;
+  f32x16 negm = {};
+  f32x16 s[2];
+  bf16x8 pb[4];                   // bf16 P of the tile whose P.V is pending: k-step st = keys 16 st .. 16 st + 15
+
+  const int tr_i = lane & 15;
+  const int tr_q = tr_i >> 2, tr_p = tr_i & 3;
+  const int tr_dcol = ((lane >> 4) & 1) * 16 + tr_p * 4;
+  const int tr_base0 = v_off(4 * lh + tr_q, tr_dcol >> 3) + (tr_dcol & 7) * 2;
+  const int tr_base1 = tr_base0 ^ 64;
+  int k_base[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) k_base[ks] = k_off(lq, ks * 2 + lh);
+
+  auto phase_end = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // Fragment registers of ONE matrix phase, filled in the vector phase before it: the matrix phase is then 20 MFMAs
+  // out of registers (640 matrix-pipe cycles, no LDS wait inside).
+  bf16x8 kfr[4][2];               // K(t+1) rows: [k-step][32-key sub tile]
+  bf16x8 vfr[4][2];               // V(t)^T:      [16-key k-step][32-dim tile]
+  auto read_k = [&](int t) {
+    const unsigned char* sk = smem + (t % NSTG) * TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) kfr[ks][u] = *reinterpret_cast<const bf16x8*>(sk + k_base[ks] + u * 32 * 128);
+  };
+  auto read_v = [&](int t) {
+    const unsigned char* sv = smem + (NSTG + t % NSTG) * TILE_BYTES;
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const int offA = (dt == 0 ? tr_base0 : tr_base1) + st * 16 * 128;
+        const int offB = offA + 8 * 128;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sv + offA));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sv + offB));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        vfr[st][dt] = __builtin_bit_cast(bf16x8, both);
+      }
+  };
+  auto pv = [&]() {               // O^T += V^T . P^T, row sums on the "ones" tile
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[st][0], pb[st], o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[st][1], pb[st], o1, 0, 0, 0);
+      ol = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones_frag, pb[st], ol, 0, 0, 0);
+    }
+  };
+  auto qk = [&]() {               // S^T = K . Q^T, started at -running max (exp2 domain)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (ks == 0) s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[0][u], qf[0], negm, 0, 0, 0);
+        else         s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[ks][u], qf[ks], s[u], 0, 0, 0);
+      }
+  };
+  auto softmax = [&](int kb) {    // exactly the arithmetic of attn_kernel<.., PRE = true>
+    if (kb * KV_TILE + KV_TILE > nk) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kb * KV_TILE + u * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (key >= nk) s[u][r] = NEG_BIG;
+        }
+    }
+    float mx = s[0][0];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[u][r]);
+    mx = pair_max(mx);
+    if (kb == 0 || !__all(mx <= RESCALE_LOG2)) {
+      const float delta = kb == 0 ? mx : fmaxf(mx, 0.f);
+      if (kb != 0) {
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        ol[0] *= alpha;
+      }
+      m_run += delta;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) negm[r] = -m_run;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[u][r] -= delta;
+    }
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pb[st][j] = (__bf16)__builtin_amdgcn_exp2f(s[st >> 1][8 * (st & 1) + j]);
+  };
+
+  // ---- prologue (all waves together): K(0..2), V(0..1) land; K(0)'s fragments go to registers
+  load_k(0); load_v(0); load_k(1); load_v(1); load_k(2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  phase_end();
+  read_k(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (grp == 1) phase_end();             // the stagger
+  for (int t = 0; t < nkb; ++t) {
+    // ---- A_t: pure MFMA
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#ifdef MVD_PROBE
+    if (!(a.dbg & 16))
+#endif
+    {
+    if (t > 0) pv();                     // P(t-1) . V(t-1)
+    qk();                                // K(t) . Q^T
+    }
+    __builtin_amdgcn_s_setprio(0);
+    phase_end();
+    // ---- B_t: softmax(t); fragments of the next matrix phase; then the loads two / three tiles ahead
+#ifdef MVD_PROBE
+    if (!(a.dbg & 4))
+#endif
+    {
+    read_v(t);                           // (first: the LDS latency hides under the exponentials)
+    if (t + 1 < nkb) read_k(t + 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef MVD_PROBE
+    if (!(a.dbg & 8))
+#endif
+    softmax(t);
+#ifdef MVD_PROBE
+    if (a.dbg & 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else
+#endif
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's loads issued at the end of B_{t-1}; this phase's reads
+#ifdef MVD_PROBE
+    if (!(a.dbg & 2))
+#endif
+    { load_k(t + 3); load_v(t + 2); }
+    phase_end();
+  }
+  // ---- drain: the last tile's P.V
+  __builtin_amdgcn_s_setprio(1);
+  pv();
+  __builtin_amdgcn_s_setprio(0);
+  phase_end();
+  if (grp == 0) phase_end();             // balance the stagger
+
+  const float inv = 1.0f / pair_sum(ol[0]);
+  if (qrow < nq) {
+    bf16_t* orow = op + (size_t)qrow * P.ldo;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      u32x2 w0 = {pack2bf(o0[4 * g] * inv, o0[4 * g + 1] * inv), pack2bf(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv)};
+      u32x2 w1 = {pack2bf(o1[4 * g] * inv, o1[4 * g + 1] * inv), pack2bf(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv)};
+      *reinterpret_cast<u32x2*>(orow + 8 * g + 4 * lh) = w0;
+      *reinterpret_cast<u32x2*>(orow + 32 + 8 * g + 4 * lh) = w1;
+    }
+  }
+}
+
+#endif  // MVD_PROBE
+
 thread_local int g_last_attn[2] = {0, 0};
 
 template <int NW, int NSUB>
@@ -556,6 +788,25 @@ int mvd_launch_attention(const MvdAttnArgs& a, hipStream_t s) {
   // (profiles/r01_probe_attention_kv128.log)
   static const int kv128 = MVD_ENV_INT("MVD_ATTN_KV128", 0);
   const bool big = kv128 != 0 && mink >= 256 && !a.prescaled;
+#ifdef MVD_PROBE
+  // EXPERIMENT (probe builds, MVD_ATTN_PP=1): the ping-pong kernel -- measured 5-15 % slower than the free-running kernels
+  // (profiles/r02_probe_attention_pingpong.log: its vector phase is twice as long as its matrix phase)
+  static const int use_pp = MVD_ENV_INT("MVD_ATTN_PP", 0);
+  const_cast<MvdAttnArgs&>(a).dbg = MVD_ENV_INT("MVD_ATTN_DBG", 0);
+  {
+    bool ok = use_pp && a.prescaled && maxq >= 256;
+    for (int i = 0; i < a.nprob && ok; ++i) ok = (size_t)a.p[i].nk * (a.p[i].ldk > a.p[i].ldv ? a.p[i].ldk : a.p[i].ldv) * 2 < ((size_t)1 << 31);
+    const long wgs = (long)((maxq + 255) / 256) * a.heads * a.batch * a.nprob;
+    if (ok && wgs >= 1024) {
+      dim3 grid((maxq + 255) / 256, a.heads, a.batch * a.nprob);
+      g_last_attn[0] = 8; g_last_attn[1] = (int)wgs;
+      hipLaunchKernelGGL(attn_pp_kernel, grid, dim3(512), 0, s, a);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) { mvd_set_error("attention (pp) launch: %s", hipGetErrorString(e)); return -3; }
+      return 0;
+    }
+  }
+#endif
   switch (mvd_attention_pick_nw(a)) {
     case 3: return launch_nw<8, 2>(a, maxq, s);
     case 2: return big ? launch_nw<4, 4>(a, maxq, s) : launch_nw<4, 2>(a, maxq, s);

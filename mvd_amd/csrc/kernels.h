@@ -74,6 +74,7 @@ struct MvdAttnArgs {
   int batch, heads;
   float scale;                    // softmax scale (1/sqrt(64))
   int prescaled;                  // 1: q is already multiplied by scale*log2(e) (host-folded into to_q); scale unused
+  int dbg;                        // probe builds only (-DMVD_PROBE, env MVD_ATTN_DBG): ablation bits of the ping-pong kernel
 };
 int mvd_launch_attention(const MvdAttnArgs& a, hipStream_t s);
 
