@@ -912,6 +912,7 @@ int mvd_op_linear(const void* a, const void* a2, int k1, int k2, const void* w, 
   g.bias = bias; g.rowvec = rowvec; g.ld_rowvec = ld_rowvec; g.res = (const bf16_t*)res;
   const int on = geglu ? n / 2 : n;
   g.ldres = on; g.alpha = alpha; g.geglu = geglu; g.out = out; g.ldo = on; g.out_f32 = out_f32;
+  g.part = splitk_ws;      // (also the stamp buffer of probe builds)
   if (splitk > 1) {
     g.splitk = splitk; g.part = splitk_ws;
     if (int r = mvd_launch_gemm(g, (hipStream_t)stream, force_cfg)) return r;

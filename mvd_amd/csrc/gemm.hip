@@ -673,7 +673,7 @@ int mvd_launch_gemm(const MvdGemmArgs& a, hipStream_t s, int force_cfg) {
       if (!legacy && !a.dbg && mvd_gemm_pp_applicable(a)) return mvd_launch_gemm_pp(a, s);
       return launch_mode2<C6, 0, true, false>(a, s);
     case 7:
-      if (!legacy && !a.dbg && !a.geglu && mvd_gemm_pp_applicable(a)) return mvd_launch_gemm_pp(a, s);
+      if (!legacy && !(a.dbg & ~32) && !a.geglu && mvd_gemm_pp_applicable(a)) return mvd_launch_gemm_pp(a, s);
 #ifdef MVD_PROBE
       if (use_ring && !a.out_f32 && !a.dbg) return mvd_launch_gemm_ring(a, s);
 #endif

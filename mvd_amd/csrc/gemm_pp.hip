@@ -19,9 +19,9 @@
 //       M0: 40 MFMAs out of registers (s_setprio 1)
 //       R1: ds_read the fragments of k 32..63 (group 0: the rest of the next slab's W loads; group 1: wait for its loads)
 //       M1: 40 MFMAs (group 0: then wait for its loads)
-//   so at any time one wave of a SIMD is in an MFMA-only phase while its partner reads LDS / issues loads / runs
-//   an epilogue: the matrix pipe always has a wave to serve.  DMAs stay in flight across barriers (raw s_barrier,
-//   explicit counted waits); a tile's epilogue runs under the partner group's MFMA phase.
+//   so at any time one wave of a SIMD is in an MFMA-only phase while its partner reads LDS / issues loads: the matrix
+//   pipe always has a wave to serve.  DMAs stay in flight across barriers (raw s_barrier, explicit waits); the epilogues
+//   of the two groups run in one common phase E per tile.
 //
 // Hazard bookkeeping (g = barrier generation; group 0 passes its p-th program barrier at g = p, group 1 at p + 1;
 // slab t occupies program barriers 4t .. 4t+3):
@@ -193,41 +193,29 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
   const int fr = lane & 15, fq = lane >> 4;
   const float alpha = a.alpha;
 
-  // accumulators start at bias + per-batch row vector (as gemm.hip)
-  auto init_acc = [&](int m0, int n0) {
-    asm volatile("" : "+s"(m0), "+s"(n0));
-    const int nb = n0 + wn * WTN + fq * 4;
+  // Accumulators start at ZERO; bias and the per-batch row vector are added by the epilogue, whose loads all precede its
+  // stores.  (gemm.hip starts the accumulators at bias + row vector, i.e. loads them AFTER the previous tile's stores:
+  // vmcnt counts loads and stores together, in order, so such a load can only be waited for by draining every store in
+  // front of it -- a full HBM write round trip per tile and wave at the top of the next slab.)
+  auto init_acc = [&]() {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (SPLITK) return;
+  };
+  // column constants of a tile: bias + (row vector of the tile's batch element, when the tile lies inside one)
+  auto load_colconst = [&](int m0, int n0, f32x4 (&cb)[TN]) {
+    const int nb = n0 + wn * WTN + fq * 4;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) cb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (a.bias) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + nb + j * 16);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) acc[i][j] = bv;
-      }
+      for (int j = 0; j < TN; ++j) cb[j] = *reinterpret_cast<const f32x4*>(a.bias + nb + j * 16);
     }
-    if (GEGLU || !a.rowvec) return;
-    if (a.rows_per_batch % BM == 0) {        // the whole tile lies in one batch element: one vector for all rows
+    if (!GEGLU && a.rowvec && a.rows_per_batch % BM == 0) {
       const float* rv = a.rowvec + (size_t)(m0 / a.rows_per_batch) * a.ld_rowvec + nb;
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const f32x4 r = *reinterpret_cast<const f32x4*>(rv + j * 16);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) acc[i][j] += r;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        int m = m0 + wm * WTM + i * 16 + fr;
-        m = m < a.M ? m : a.M - 1;
-        const float* rv = a.rowvec + (size_t)(m / a.rows_per_batch) * a.ld_rowvec + nb;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] += *reinterpret_cast<const f32x4*>(rv + j * 16);
-      }
+      for (int j = 0; j < TN; ++j) cb[j] += *reinterpret_cast<const f32x4*>(rv + j * 16);
     }
   };
 
@@ -265,12 +253,14 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
       // column tiles (j, j+1) = (value, gate) of ONE 16-wide output tile; output tiles are then paired for 16-byte stores
       constexpr int NO = TN / 2;                           // output column tiles per wave
       const int oc0 = (n0 + wn * WTN) / 2;
+      f32x4 cb[TN];
+      load_colconst(m0, n0, cb);
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         u32x2 o[NO];
 #pragma unroll
         for (int q = 0; q < NO; ++q) {
-          const f32x4 v = acc[i][2 * q], g = acc[i][2 * q + 1];    // bias already in
+          const f32x4 v = acc[i][2 * q] + cb[2 * q], g = acc[i][2 * q + 1] + cb[2 * q + 1];
           o[q] = u32x2{pack2bf(v[0] * gelu_erf_f(g[0]), v[1] * gelu_erf_f(g[1])), pack2bf(v[2] * gelu_erf_f(g[2]), v[3] * gelu_erf_f(g[3]))};
         }
         const int so = ((row0 + i * 16) * a.ldo + oc0) * 2;
@@ -287,6 +277,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
       if (has_res) rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.res), 0, (int)((size_t)a.M * a.ldres * 2), 0x00020000);
       const int vr16 = (fr * a.ldres + pair_col) * 2, vr8 = (fr * a.ldres + fq * 4) * 2;
       constexpr int NP = TN / 2;                           // column-tile pairs (+ one single tile when TN is odd)
+      f32x4 cb[TN];
+      load_colconst(m0, n0, cb);
+      const bool row_rv = a.rowvec && a.rows_per_batch % BM != 0;   // a tile straddling batch elements (maps < 256 pixels): per-row vectors
       // residual rows are fetched for RG row tiles at a time (one memory round trip per batch, not per row tile)
       constexpr int RG = HAS_CONV ? 2 : 4;
 #pragma unroll
@@ -306,7 +299,12 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
         for (int g = 0; g < RG; ++g) {
           const int i = i0 + g;
           const int so = ((row0 + i * 16) * a.ldo + n0 + wn * WTN) * 2;
-          auto finish = [&](f32x4 v, u32x2 r) -> u32x2 {
+          int mrow = row0 + i * 16 + fr;
+          mrow = mrow < a.M ? mrow : a.M - 1;
+          const float* rvp = row_rv ? a.rowvec + (size_t)(mrow / a.rows_per_batch) * a.ld_rowvec + n0 + wn * WTN + fq * 4 : nullptr;
+          auto finish = [&](f32x4 v, int j, u32x2 r) -> u32x2 {
+            v += cb[j];
+            if (row_rv) v += *reinterpret_cast<const f32x4*>(rvp + j * 16);
             v *= alpha;
             if (has_res) { v[0] += bflo(r[0]); v[1] += bfhi(r[0]); v[2] += bflo(r[1]); v[3] += bfhi(r[1]); }
             return u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
@@ -318,11 +316,11 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
               ra = u32x2{rp[g][q][0], rp[g][q][1]}; rb = u32x2{rp[g][q][2], rp[g][q][3]};
               swap_pair(ra, rb);
             }
-            u32x2 oa = finish(acc[i][2 * q], ra), ob = finish(acc[i][2 * q + 1], rb);
+            u32x2 oa = finish(acc[i][2 * q], 2 * q, ra), ob = finish(acc[i][2 * q + 1], 2 * q + 1, rb);
             swap_pair(oa, ob);
             __builtin_amdgcn_raw_buffer_store_b128(u32x4{oa[0], oa[1], ob[0], ob[1]}, rs_o, vo16, so + q * 64, 0);
           }
-          if (TN & 1) __builtin_amdgcn_raw_buffer_store_b64(finish(acc[i][TN - 1], has_res ? rs1[g] : u32x2{0u, 0u}), rs_o, vo8, so + (TN - 1) * 32, 0);
+          if (TN & 1) __builtin_amdgcn_raw_buffer_store_b64(finish(acc[i][TN - 1], TN - 1, has_res ? rs1[g] : u32x2{0u, 0u}), rs_o, vo8, so + (TN - 1) * 32, 0);
         }
       }
     }
@@ -360,9 +358,22 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
   };
   // phase boundary: nothing moves across it at compile time; the barrier itself is the raw s_barrier (no implied
   // vmcnt(0): LDS-DMAs stay in flight across it)
+#ifdef MVD_PROBE
+  // probe builds, MVD_GEMM_DEBUG & 32: shader-clock stamps at every phase boundary of waves 0 and 4 of the first 64
+  // workgroups into the (otherwise unused) split-K partial buffer: [wg][grp][512] -- tools/probe_pp_stamps.py
+  int stamp_n = 0;
+  long long* stamp_p = ((a.dbg & 32) && a.part && blockIdx.x < 64 && (wave & 3) == 0 && lane == 0)
+                           ? reinterpret_cast<long long*>(a.part) + ((size_t)blockIdx.x * 2 + grp) * 512 : nullptr;
+#endif
   auto phase_end = [&]() {
     __builtin_amdgcn_sched_barrier(0);
+#ifdef MVD_PROBE
+    if (stamp_p && stamp_n < 511) stamp_p[1 + stamp_n++] = (long long)__builtin_amdgcn_s_memtime();   // arrival at the barrier
+#endif
     __builtin_amdgcn_s_barrier();
+#ifdef MVD_PROBE
+    if (stamp_p && stamp_n < 511) { stamp_p[1 + stamp_n++] = (long long)__builtin_amdgcn_s_memtime(); stamp_p[0] = stamp_n; }   // release
+#endif
     __builtin_amdgcn_sched_barrier(0);
   };
 
@@ -372,15 +383,20 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
   setup_loader(tile);
   issue_a(0, kt0);
   if (grp == 0) issue_w(0, kt0, 0, W_Q);
-  {
-    const int tl0 = S == 1 ? tile : tile / S;
-    init_acc((tl0 / ntn) * BM, (tl0 % ntn) * BN);
-  }
+  init_acc();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   phase_end();
   if (grp == 1) phase_end();             // the stagger: group 1 runs one phase behind group 0 from here on
 
+  // A finished tile's epilogue (bias / residual loads, ~24 stores: several thousand cycles of memory round trips) is its
+  // own phase "E" in which BOTH groups run theirs at the same time (group 0 idles one phase in front of it, group 1 one
+  // phase behind it, so the one-phase stagger survives; the fragment registers are dead in E, which the epilogue's
+  // temporaries need).  Run back to back instead (each group's epilogue under one 700-cycle MFMA phase of the other), the two
+  // epilogues SERIALISE: in-kernel stamps showed 8-21 thousand cycles per group per tile, 50-100 % on top of a five-slab
+  // tile (profiles/r02_probe_pp_phase_stamps.log).
   int cur = 0;
+  bool pend = false;                    // the previous work item's epilogue is still to run
+  int pm0 = 0, pn0 = 0, pks = 0;
   for (;;) {
     const int tl = S == 1 ? tile : tile / S;
     const int ks = S == 1 ? 0 : tile - tl * S;
@@ -393,6 +409,14 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
       const bool last_k = kt + 1 == kt1;
       const bool more = !last_k || have_next;
       const int nlk = last_k ? nkt0 : kt + 1;          // the slab being fetched
+      if (pend) {                                      // ---- E: both groups' epilogues in one common phase
+        if (grp == 0) phase_end();                     //   group 0 idles through group 1's last M1 ...
+        epilogue(pm0, pn0, pks);
+        init_acc();
+        phase_end();
+        if (grp == 1) phase_end();                     //   ... group 1 through group 0's first R0: the stagger is back
+        pend = false;
+      }
       // ---- R0
       read_frags(cur, 0);
       if (more) {
@@ -418,18 +442,13 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
       mfma_half();
       if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // group 0's loads (R0 + R1) have landed: one MFMA phase of cover
       phase_end();
-      if (last_k) {            // under the partner group's MFMA phase
-        epilogue(m0, n0, ks);
-        if (have_next) {
-          const int tn = S == 1 ? next_tile : next_tile / S;
-          init_acc((tn / ntn) * BM, (tn % ntn) * BN);
-        }
-      }
+      if (last_k) { pend = true; pm0 = m0; pn0 = n0; pks = ks; }
       cur ^= 1;
     }
     if (!have_next) break;
     tile = next_tile; kt0 = nkt0; kt1 = nkt1;
   }
+  epilogue(pm0, pn0, pks);               // the last work item's
   if (grp == 0) phase_end();             // balance the extra barrier group 1 executed up front
 }
 
