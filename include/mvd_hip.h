@@ -104,7 +104,8 @@ int mvd_unet_forward(mvd_engine_t* e, const mvd_forward_args_t* args, void* stre
 int mvd_engine_share_encoder_weights(mvd_engine_t* e, int enable);
 
 /* Per-kernel-class timing with HIP events on the launch stream (measurement only; off by default).
- * classes: 0..7 GEMM/conv tile config, 12 the 128x320 tile, 8..11 attention (1,2,4,8 waves), 16 groupnorm, 17 layernorm. */
+ * classes = kernels: 0..5, 12 lock-step GEMM/conv tile configs (gemm.hip); ping-pong 256x320 kernels (gemm_pp.hip): 7 dense,
+ * 13 implicit-GEMM 3x3 convolution, 14 split-K, 6 GEGLU; 8..11 attention (1,2,4,8 waves); 16 groupnorm; 17 layernorm. */
 int mvd_engine_set_profiling(mvd_engine_t* e, int enable);
 int mvd_engine_profile_summary(mvd_engine_t* e, int cap, int* cls, int* launches, double* ms, double* flops, double* bytes);
 /* Per-shape text table ("cls M N K tag launches ms tflops" per line) of the launches recorded since profiling was

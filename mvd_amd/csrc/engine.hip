@@ -81,7 +81,14 @@ struct mvd_engine {
 
 // profiling classes: 0..5 = gemm tile config, 8..11 = attention NW (1,2,4,8), 16 groupnorm, 17 layernorm, 18 other
 int mvd_gemm_pick_config(const MvdGemmArgs& a);
-static inline int gemm_class(int cfg) { return cfg == 8 ? 12 : cfg; }   // profile classes 8..11 are the attention kernels
+// profile class of a GEMM launch = the KERNEL that runs it (each is a distinct rocprof kernel name): tile config for the
+// lock-step kernels of gemm.hip; for the ping-pong kernels of gemm_pp.hip 7 = dense A operand, 13 = implicit-GEMM 3x3
+// convolution (incl. the fused 1x1 shortcut / upsample forms), 14 = their split-K forms, 6 = GEGLU.  (8..11 are attention.)
+static inline int gemm_class(const MvdGemmArgs& g, int cfg, int splitk) {
+  if (cfg == 8) return 12;
+  if (cfg == 7) return splitk > 1 ? 14 : (g.seg[0].mode == MVD_A_CONV3 ? 13 : 7);
+  return cfg;
+}
 int mvd_attention_pick_nw(const MvdAttnArgs& a);
 
 namespace {
@@ -141,7 +148,7 @@ struct Ctx {
     if (!dry) {
       const double fl = 2.0 * g.M * (double)g.N * g.Ktot;
       e->prof_M = g.M; e->prof_N = g.N; e->prof_K = g.Ktot; e->prof_tag = g.seg[0].mode * 100 + g.geglu * 10 + (S > 1 ? S : 0);
-      r = profiled(e->prof ? gemm_class(mvd_gemm_pick_config(g)) : 0, fl, 0.0, [&] { return mvd_launch_gemm(g, s); });
+      r = profiled(e->prof ? gemm_class(g, mvd_gemm_pick_config(g), S) : 0, fl, 0.0, [&] { return mvd_launch_gemm(g, s); });
       if (!r && S > 1) r = mvd_launch_splitk_reduce(g, s);
     }
     e->tmp.off = mark;
@@ -182,10 +189,12 @@ struct Ctx {
     float* ws = talloc<float>((size_t)B * MVD_GN_MAXCHUNK * groups * 2);
     if (dry) return 0;
     const double by = 3.0 * B * (double)hw * (c0 + c1) * 2;   // 2 reads + 1 write of the activation
+    e->prof_M = B * hw; e->prof_N = c0 + c1; e->prof_K = 0; e->prof_tag = 2000 + silu;
     return profiled(16, 0.0, by, [&] { return mvd_launch_groupnorm(x0, x1, c0, c1, B, hw, groups, eps, g, b, silu, y, ws, s); });
   }
   int layernorm(const bf16_t* x, int rows, int c, const float* g, const float* b, bf16_t* y) {
     if (err) return err; if (dry) return 0;
+    e->prof_M = rows; e->prof_N = c; e->prof_K = 0; e->prof_tag = 3000;
     return profiled(17, 0.0, 2.0 * rows * (double)c * 2, [&] { return mvd_launch_layernorm(x, rows, c, 1e-5f, g, b, y, s); });
   }
   int attention(MvdAttnArgs& a) {

@@ -3,10 +3,12 @@
 
 gfx950 corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts 64 B per 128-B request for wide
 coalesced reads -> doubled; WRITE_SIZE is exact for 16-B stores; both are in KB."""
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, re, sys
 
 CLASSES = {
-    "gemm_256x320": "Cfg<256, 320, 2, 4>", "gemm_256x320_geglu": "Cfg<256, 320, 4, 2>", "gemm_128x160": "Cfg<128, 160, 2, 2>",
+    "gemm_pp_256x320_dense": r"gemm_pp_kernel<256, 2, 4, 0, false>", "gemm_pp_256x320_conv3x3": r"gemm_pp_kernel<256, 2, 4, [123], false>",
+    "gemm_pp_256x320_splitk": r"gemm_pp_kernel<256, 2, 4, \d, true>", "gemm_pp_256x320_geglu": r"gemm_pp_kernel<256, 4, 2, 0, false>",
+    "gemm_128x160": "Cfg<128, 160, 2, 2>",
     "gemm_128x128": "Cfg<128, 128, 2, 2>", "gemm_128x64": "Cfg<128, 64, 2, 2>", "gemm_64x64": "Cfg<64, 64, 2, 2>",
     "attn_4wave": "attn_kernel<4,", "attn_8wave": "attn_kernel<8,", "attn_2wave": "attn_kernel<2,", "attn_1wave": "attn_kernel<1,",
     "groupnorm": "gn_", "layernorm": "ln_kernel",
@@ -24,12 +26,12 @@ def main(fetch_dir, write_dir, out):
     w = agg(glob.glob(write_dir + "/*/*counter_collection.csv")[0])
     res = {}
     for cls, pat in CLASSES.items():
-        n = sum(v[0] for k, v in f.items() if pat in k)
+        n = sum(v[0] for k, v in f.items() if re.search(pat if pat.startswith('gemm_pp') else re.escape(pat), k))
         if not n:
             continue
-        fk = sum(v[1] for k, v in f.items() if pat in k)
-        wk = sum(v[1] for k, v in w.items() if pat in k)
-        nw = sum(v[0] for k, v in w.items() if pat in k)
+        fk = sum(v[1] for k, v in f.items() if re.search(pat if pat.startswith('gemm_pp') else re.escape(pat), k))
+        wk = sum(v[1] for k, v in w.items() if re.search(pat if pat.startswith('gemm_pp') else re.escape(pat), k))
+        nw = sum(v[0] for k, v in w.items() if re.search(pat if pat.startswith('gemm_pp') else re.escape(pat), k))
         res[cls] = {"launches": n, "fetch_bytes_per_launch": 2.0 * fk * 1024 / n, "write_bytes_per_launch": wk * 1024 / max(nw, 1),
                     "hbm_bytes_per_launch": 2.0 * fk * 1024 / n + wk * 1024 / max(nw, 1),
                     "note": "FETCH_SIZE x2 (gfx950 128-B requests tallied at 64 B) + WRITE_SIZE, KB -> bytes"}
