@@ -183,6 +183,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && NSUB == 2) ? 3 : 2) void attn_
         else         s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t], 0, 0, 0);
       }
     }
+
     // ---- mask keys beyond nk (only the last tile can be ragged)
     if (kb * KV_TILE + KV_TILE > nk) {
 #pragma unroll

@@ -695,7 +695,12 @@ int mvd_gemm_pick_splitk(const MvdGemmArgs& a) {
   if (tiles >= 256 || nkt < 16) return 1;
   long s = 512 / tiles;                                       // two workgroups per CU
   if (s > nkt / 8) s = nkt / 8;
-  if (s > 4) s = 4;                                           // partial-sum traffic grows with the split
+  // the fp32 partials (written and read back: 8 S M N bytes) against the weight bytes the split spreads over more CUs
+  // (2 N K): up to 4 always, deeper while the partials stay below the weights -- the 8x8 / 16x16 levels at small batch
+  // are pure weight streaming (M = 64, K = 11520: 29 MB of weights, 20 tiles), which a 4-way split leaves on 80 CUs
+  long cap = (long)a.Ktot / (4L * a.M);
+  cap = cap < 4 ? 4 : (cap > 16 ? 16 : cap);
+  if (s > cap) s = cap;
   return s < 2 ? 1 : (int)s;
 }
 
