@@ -58,16 +58,18 @@ def fill_synthetic_weights(model, seed: int = 0):
 
 
 def make_batch(pairs: int, rank: int, device):
-    """8 objects x 4 target views per 32 pairs.  As pipeline.py:111-116 does, each object's source IMAGE is repeated per
-    view (so text and source latents repeat 4x here); the reference then draws ``latent_dist.sample()`` per row, which a
-    deterministic synthetic batch does not imitate -- the engine makes no use of the repetition either way."""
+    """8 objects x 4 target views per 32 pairs.  As pipeline.py:111-116 does, each object's source IMAGE (and prompt) is
+    repeated per view, and ``latent_dist.sample()`` then draws a separate latent per ROW: the text rows repeat 4x, the
+    32 source latents are distinct (a shared per-object mean plus per-row posterior noise).  The engine makes no use of
+    any repetition."""
     from mvd_amd.utils import look_at
     g = torch.Generator().manual_seed(1000 + rank)
     objs = max(1, pairs // 4)
     views = pairs // objs
     sample = torch.randn(pairs, 4, 64, 64, generator=g)
     text = torch.randn(objs, 77, 1024, generator=g).repeat_interleave(views, 0)
-    lat = (0.18215 * torch.randn(objs, 4, 64, 64, generator=g)).repeat_interleave(views, 0)   # pipeline.py:111-113
+    mean = torch.randn(objs, 4, 64, 64, generator=g).repeat_interleave(views, 0)              # pipeline.py:111-113
+    lat = 0.18215 * (mean + 0.1 * torch.randn(pairs, 4, 64, 64, generator=g))                  # pipeline.py:115-116
     src = torch.stack([look_at(0.0)] * pairs)
     tgt = torch.stack([look_at([45.0, 90.0, 180.0, 270.0][i % 4]) for i in range(pairs)])
     t = torch.full((pairs,), 500.0)

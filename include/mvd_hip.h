@@ -133,6 +133,13 @@ int mvd_op_linear(const void* a, const void* a2, int k1, int k2, const void* w, 
                   int ld_rowvec, int rows_per_batch, const void* res, float alpha, int geglu, void* out, int out_f32,
                   int m, int n, int force_cfg, int splitk, float* splitk_ws /* splitk*m*n floats when splitk > 1 */,
                   void* stream);
+/* out[M][N] = LayerNorm(x[M][K]; gamma, beta, eps) . W^T + b in ONE kernel (geglu = 1: followed by value*gelu(gate), width
+ * N/2, rows interleaved as for mvd_op_linear).  w_folded = W.diag(gamma) in bf16, c1[n] = sum_k w_folded[n][k] (of the bf16
+ * values, fp32), c2[n] = sum_k beta[k].W[n][k] + b[n]: mvd_amd/packing.py::fold_layernorm.  Shapes: K <= 1280, N % 320 == 0
+ * and enough rows for the 256x320 tile grid (M*N >= 200 tiles); anything else returns an error (the engine then runs the
+ * LayerNorm kernel + mvd_op_linear). */
+int mvd_op_ln_linear(const void* x, int k, const void* w_folded, const float* c1, const float* c2, float eps, int geglu,
+                     void* out, int m, int n, void* stream);
 /* 3x3 conv (pad 1) on NHWC bf16 as implicit GEMM; optional fused 1x1 shortcut on (sc, sc2).  asym_pad = 1 (stride 2 only):
  * zero padding on the bottom/right edge only -- diffusers' VAE Downsample2D(padding=0). */
 int mvd_op_conv3x3(const void* x, int batch, int in_h, int in_w, int cin, int stride, int upsample, int asym_pad, const void* w,

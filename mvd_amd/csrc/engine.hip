@@ -80,13 +80,13 @@ struct mvd_engine {
 };
 
 // profiling classes: 0..5 = gemm tile config, 8..11 = attention NW (1,2,4,8), 16 groupnorm, 17 layernorm, 18 other
-int mvd_gemm_pick_config(const MvdGemmArgs& a);
 // profile class of a GEMM launch = the KERNEL that runs it (each is a distinct rocprof kernel name): tile config for the
 // lock-step kernels of gemm.hip; for the ping-pong kernels of gemm_pp.hip 7 = dense A operand, 13 = implicit-GEMM 3x3
-// convolution (incl. the fused 1x1 shortcut / upsample forms), 14 = their split-K forms, 6 = GEGLU.  (8..11 are attention.)
+// convolution (incl. the fused 1x1 shortcut / upsample forms), 14 = their split-K forms, 15 = dense with the LayerNorm fold,
+// 6 = GEGLU (with or without the fold).  (8..11 are attention.)
 static inline int gemm_class(const MvdGemmArgs& g, int cfg, int splitk) {
   if (cfg == 8) return 12;
-  if (cfg == 7) return splitk > 1 ? 14 : (g.seg[0].mode == MVD_A_CONV3 ? 13 : 7);
+  if (cfg == 7) return splitk > 1 ? 14 : (g.seg[0].mode == MVD_A_CONV3 ? 13 : (g.ln_c1 ? 15 : 7));
   return cfg;
 }
 int mvd_attention_pick_nw(const MvdAttnArgs& a);
@@ -163,6 +163,26 @@ struct Ctx {
     g.seg[0].p0 = a; g.seg[0].p1 = a2; g.seg[0].c0 = k1; g.seg[0].c1 = k2; g.seg[0].mode = MVD_A_DENSE; g.seg[0].ksize = k1 + k2;
     g.nseg = 1; g.W = w; g.M = M; g.N = N; g.Ktot = k1 + k2; g.rows_per_batch = M; g.outH = 1; g.outW = M;
     g.bias = bias; g.res = res; g.ldres = ldres; g.alpha = 1.f; g.geglu = geglu; g.out = out; g.ldo = ldo; g.out_f32 = out_f32;
+    return gemm(g);
+  }
+
+  // out = LayerNorm(x; gamma, beta).W^T + b (optionally GEGLU).  With the folded slots <slot>.wf (W.diag(gamma), bf16) and
+  // <slot>.cf ([2][n_full]: c1 | c2) registered and a shape the fused kernel takes, ONE launch (gemm_pp.hip, LNF) that reads
+  // the un-normalised rows; otherwise ln_kernel into `ln_tmp` and the plain GEMM.
+  int ln_linear(const bf16_t* x, int M, int C, const std::string& ln_key, const std::string& slot, int64_t n_full, int N,
+                const float* bias, bf16_t* ln_tmp, void* out, int ldo, bool geglu) {
+    MvdGemmArgs g; memset(&g, 0, sizeof(g));
+    g.ldw = C; g.seg[0].p0 = x; g.seg[0].c0 = C; g.seg[0].mode = MVD_A_DENSE; g.seg[0].ksize = C; g.nseg = 1;
+    g.M = M; g.N = N; g.Ktot = C; g.rows_per_batch = M; g.outH = 1; g.outW = M; g.alpha = 1.f; g.geglu = geglu; g.out = out; g.ldo = ldo;
+    static const bool use_fold = MVD_ENV_INT("MVD_LN_FOLD", 1) != 0;
+    if (use_fold && !dry && has(slot + ".wf") && has(slot + ".cf") && mvd_gemm_ln_fold_ok(g)) {
+      const float* cf = WF(slot + ".cf", 2 * n_full);
+      g.W = WB(slot + ".wf", n_full * C);
+      g.ln_c1 = cf; g.bias = cf ? cf + n_full : nullptr; g.ln_eps = 1e-5f;
+      return gemm(g);
+    }
+    CHECK(layernorm(x, M, C, WF(ln_key + ".g", C), WF(ln_key + ".b", C), ln_tmp));
+    g.seg[0].p0 = ln_tmp; g.W = WB(slot + ".w", n_full * C); g.bias = bias;
     return gemm(g);
   }
 
@@ -317,8 +337,7 @@ struct UNetPass {
     {
       const int nq = ad ? 4 * C : 3 * C;
       bf16_t* qkv = c.talloc<bf16_t>((size_t)M * nq);
-      CHECK(c.layernorm(h, M, C, c.WF(key + ".ln1.g", C), c.WF(key + ".ln1.b", C), ln));
-      CHECK(c.linear(ln, nullptr, C, 0, M, c.WB(key + ".attn1.qkv.w", (int64_t)(packed ? 4 : 3) * C * C), nullptr, nq, nullptr, 0, qkv, nq));
+      CHECK(c.ln_linear(h, M, C, key + ".ln1", key + ".attn1.qkv", (int64_t)(packed ? 4 : 3) * C, nq, nullptr, ln, qkv, nq, false));
       MvdAttnArgs a; memset(&a, 0, sizeof(a));
       a.batch = B_; a.heads = heads; a.scale = scale; a.prescaled = 1; a.nprob = ad ? 2 : 1;
       a.p[0] = {qkv, qkv + C, qkv + 2 * C, o_self, nq, nq, nq, C, (int64_t)hw * nq, (int64_t)hw * nq, (int64_t)hw * nq, (int64_t)hw * C, hw, hw};
@@ -334,8 +353,7 @@ struct UNetPass {
       bf16_t* q2 = c.talloc<bf16_t>((size_t)M * nq);
       const bf16_t* kv2 = tkv + c.e->tkv_off[feat_idx];   // [B*L][2C] slice of the fused text K/V
       const int ldkv = c.e->tkv_total;
-      CHECK(c.layernorm(h, M, C, c.WF(key + ".ln2.g", C), c.WF(key + ".ln2.b", C), ln));
-      CHECK(c.linear(ln, nullptr, C, 0, M, c.WB(key + ".attn2.q.w", (int64_t)(packed ? 2 : 1) * C * C), nullptr, nq, nullptr, 0, q2, nq));
+      CHECK(c.ln_linear(h, M, C, key + ".ln2", key + ".attn2.q", (int64_t)(packed ? 2 : 1) * C, nq, nullptr, ln, q2, nq, false));
       MvdAttnArgs a; memset(&a, 0, sizeof(a));
       a.batch = B_; a.heads = heads; a.scale = scale; a.prescaled = 1; a.nprob = ad ? 2 : 1;
       a.p[0] = {q2, kv2, kv2 + C, o_self, nq, ldkv, ldkv, C, (int64_t)hw * nq, (int64_t)L * ldkv, (int64_t)L * ldkv, (int64_t)hw * C, hw, L};
@@ -348,8 +366,7 @@ struct UNetPass {
     // ---- GEGLU feed-forward
     {
       bf16_t* ff = c.talloc<bf16_t>((size_t)M * 4 * C);
-      CHECK(c.layernorm(h, M, C, c.WF(key + ".ln3.g", C), c.WF(key + ".ln3.b", C), ln));
-      CHECK(c.linear(ln, nullptr, C, 0, M, c.WB(key + ".ff1.w", (int64_t)8 * C * C), c.WF(key + ".ff1.b", 8 * C), 8 * C, nullptr, 0, ff, 4 * C, true));
+      CHECK(c.ln_linear(h, M, C, key + ".ln3", key + ".ff1", (int64_t)8 * C, 8 * C, c.WF(key + ".ff1.b", 8 * C), ln, ff, 4 * C, true));
       CHECK(c.linear(ff, nullptr, 4 * C, 0, M, c.WB(key + ".ff2.w", (int64_t)C * 4 * C), c.WF(key + ".ff2.b", C), C, h, C, h, C));
     }
     CHECK(c.linear(h, nullptr, C, 0, M, c.WB(key + ".proj_out.w", (int64_t)C * C), c.WF(key + ".proj_out.b", C), C, x.p, C, out.p, C));
@@ -928,6 +945,17 @@ int mvd_op_linear(const void* a, const void* a2, int k1, int k2, const void* w, 
     return mvd_launch_splitk_reduce(g, (hipStream_t)stream);
   }
   return mvd_launch_gemm(g, (hipStream_t)stream, force_cfg);
+}
+
+int mvd_op_ln_linear(const void* x, int k, const void* w_folded, const float* c1, const float* c2, float eps, int geglu,
+                     void* out, int m, int n, void* stream) {
+  MvdGemmArgs g; memset(&g, 0, sizeof(g));
+  g.seg[0].p0 = (const bf16_t*)x; g.seg[0].c0 = k; g.seg[0].mode = MVD_A_DENSE; g.seg[0].ksize = k; g.nseg = 1;
+  g.W = (const bf16_t*)w_folded; g.M = m; g.N = n; g.Ktot = k; g.ldw = k; g.rows_per_batch = m; g.outH = 1; g.outW = m;
+  g.bias = c2; g.ln_c1 = c1; g.ln_eps = eps; g.alpha = 1.f; g.geglu = geglu; g.out = out; g.ldo = geglu ? n / 2 : n; g.ldres = g.ldo;
+  if (!c1 || !c2) { mvd_set_error("mvd_op_ln_linear: c1 and c2 are required"); return -1; }
+  if (!mvd_gemm_ln_fold_ok(g)) { mvd_set_error("mvd_op_ln_linear: M=%d N=%d K=%d geglu=%d is not a shape of the fused LayerNorm GEMM (mvd_gemm_ln_fold_ok)", m, n, k, geglu); return -1; }
+  return mvd_launch_gemm(g, (hipStream_t)stream);
 }
 
 int mvd_op_conv3x3(const void* x, int batch, int in_h, int in_w, int cin, int stride, int upsample, int asym_pad, const void* w,

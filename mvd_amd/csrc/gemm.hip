@@ -660,6 +660,9 @@ int mvd_launch_gemm(const MvdGemmArgs& a, hipStream_t s, int force_cfg) {
   if (cfg == 14) { glds = true; cfg = 8; }       // force_cfg 14 = the 128x320 tile (LDS-DMA only)
   else if (cfg >= 8 && cfg < 14) { glds = true; cfg -= 8; } else if (cfg >= 0 && cfg < 6) { glds = false; }
   if (cfg < 0) cfg = mvd_gemm_pick_config(a);
+  if (a.ln_c1) {   // LayerNorm fold: exists in the ping-pong kernels only (callers ask mvd_gemm_ln_fold_ok first)
+    if ((cfg != 6 && cfg != 7) || legacy || a.dbg || !mvd_gemm_ln_fold_ok(a)) { mvd_set_error("gemm: LayerNorm fold not available for M=%d N=%d K=%d cfg=%d", a.M, a.N, a.Ktot, cfg); return -1; }
+  }
   if (cfg < 0 || cfg >= kNumCfgs || a.N % kCfgs[cfg].bn || (a.geglu && !kCfgs[cfg].tn_even)) { mvd_set_error("gemm: no tile config for N=%d geglu=%d cfg=%d", a.N, a.geglu, cfg); return -1; }
   g_mvd_last_gemm.cfg = cfg; g_mvd_last_gemm.splitk = a.splitk > 1 ? a.splitk : 1;
   switch (cfg) {

@@ -42,6 +42,25 @@ constexpr unsigned OOB = 0x80000000u;                   // voffset of a load tha
 
 typedef __attribute__((address_space(3))) void lds_void;
 
+// lane id computed on the spot (2 vector ops) and opaque to the optimiser: whatever is derived from it is neither hoisted
+// out of a loop nor kept live across one
+MVD_DEVINL int fresh_lane() {
+  int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  asm volatile("" : "+v"(l));
+  return l;
+}
+
+// 16-byte buffer store + the wait states hipcc does not insert.  A store of more than 64 bits reads its data registers
+// over several cycles; overwriting them in the next instruction corrupts the last lanes' data.  hipcc's hazard
+// recognizer skips this case whenever the store's soffset is an SGPR -- as it always is here -- which the older ISAs
+// allowed; on gfx950 it is not safe: in the LayerNorm-fold epilogue a v_pk_mul_f32 directly behind a
+// buffer_store_dwordx4 replaced bf16 pairs of lanes 12..15 / 28..31 / ... by halves of the fp32 product (NaNs in the
+// output).  The asm READS the data registers, so whatever overwrites them is ordered behind the two wait states.
+MVD_DEVINL void store16(u32x4 v, __amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, soff, 0);
+  asm volatile("s_nop 1" :: "v"(v));
+}
+
 MVD_DEVINL int swz_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 // one 16-byte-per-lane LDS-DMA: LDS destination = wave-uniform base + lane * 16
@@ -53,8 +72,19 @@ MVD_DEVINL void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_wave_base,
 // up inside a wave) for GEGLU.  AMODE: 0 dense, 1 conv, 2 conv + dense (1x1 shortcut) segment, 3 conv behind a fused
 // nearest-2x upsample.
 // BM = 256 rows per tile (the default) or 128 (levels whose 256-row grid cannot fill the chip: twice the tiles, wave tile 64 x 80).
-template <int BM, int WM, int WN, int AMODE, bool SPLITK>
+//
+// LNF: LayerNorm of the A rows folded in (MvdGemmArgs::ln_c1; W carries gamma, the epilogue applies
+//   out = rstd[m] * (acc - mean[m] * c1[n]) + c2[n]).  The row statistics are accumulated from the very fragments the MFMAs
+// consume (v_dot2c_f32_bf16 in the shadow of the matrix pipe), so the normalised activation is never written or re-read
+// and there is no LayerNorm kernel.  The WN waves that share a block of rows split its row tiles between them (TM / WN
+// each) and trade (rstd, -rstd * mean) through a 6 KB exchange area behind the two LDS stages; the tile's column
+// constants c1 / c2 are LDS-DMA'd into the same area at the tile's first slab (they are only needed by its epilogue, and
+// 2 x TN x 4 registers for them do not exist in this kernel).
+constexpr int XCH_C1 = 0, XCH_C2 = 2048, XCH_STATS = 4096, XCH_BYTES = 6144;
+
+template <int BM, int WM, int WN, int AMODE, bool SPLITK, bool LNF = false>
 __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
+  static_assert(!LNF || (AMODE == 0 && !SPLITK), "the LayerNorm fold is a dense, unsplit form");
   constexpr int A_BYTES = BM * 128, STAGE_BYTES = A_BYTES + B_BYTES;
   constexpr int A_IT = BM * 8 / NT;                       // A-side DMA instructions per wave per slab (4 / 2)
   constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 16, TN = WTN / 16;
@@ -91,7 +121,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
   const int conv_rowB = cs.inW * conv_c2;             // bytes per input row
   constexpr bool conv_ups = UPS;
   const int limH = conv_ups ? 2 * cs.inH : cs.inH, limW = conv_ups ? 2 * cs.inW : cs.inW;
-  const int dc0 = ds.c0, dc1 = ds.c1;
+  const int dc0 = ds.c0, dc1 = LNF ? 0 : ds.c1;     // (LNF: one source)
 
   // ---- buffer descriptors (scalar).  The conv descriptor starts one row + one pixel BEFORE the feature map so
   // that tap (dy, dx) is a non-negative scalar offset (dy * row + dx * pixel) from a per-lane base; nothing below
@@ -167,7 +197,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
       }
     } else {
       const int cc = (lk - nkt_conv) << 6;             // first K column of the slab inside the dense segment
-      const bool first = cc < dc0;
+      const bool first = LNF || cc < dc0;
       const int pitch = (first ? dc0 : dc1) * 2;
       const unsigned col2 = (unsigned)((first ? cc : cc - dc0) * 2);
 #pragma unroll
@@ -190,6 +220,11 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
   };
 
   f32x4 acc[TM][TN];
+  // LNF: for the wave's TS row tiles (wn * TS + t), this lane's share (its 8 of every 32 k) of sum x and sum x^2 of row fr
+  constexpr int TS = TM / WN;
+  static_assert(!LNF || (TS * WN == TM && WM * TM * 16 * 8 <= XCH_BYTES - XCH_STATS && BN * 4 <= XCH_C2 - XCH_C1), "exchange area layout");
+  float row_s[LNF ? TS : 1], row_q[LNF ? TS : 1];
+  unsigned char* const xch = smem + 2 * STAGE_BYTES;
   const int fr = lane & 15, fq = lane >> 4;
   const float alpha = a.alpha;
 
@@ -202,6 +237,42 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (LNF) {
+#pragma unroll
+      for (int t = 0; t < TS; ++t) { row_s[t] = 0.f; row_q[t] = 0.f; }
+    }
+  };
+  // LNF: column constants of tile column n0 -> exchange area (wave 0: c1, wave 1: c2; 320 floats = 1.25 wave-loads each,
+  // columns beyond N read as zeros).  Issued in the first R0 of a tile, i.e. behind the barrier that closed the previous
+  // tile's epilogue (their last reader); waited for with the slab's other DMAs.
+  auto issue_consts = [&](int n0) {
+    if constexpr (LNF) {
+      if (wave < 2) {
+        __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wave == 0 ? a.ln_c1 : a.bias), 0, a.N * 4, 0x00020000);
+        unsigned char* dst = xch + (wave == 0 ? XCH_C1 : XCH_C2);
+        const unsigned vo = (unsigned)fresh_lane() * 16u;
+        dma16(rs_k, dst, vo, n0 * 4);
+        dma16(rs_k, dst + 1024, vo, n0 * 4 + 1024);
+      }
+    }
+  };
+  // LNF: finish the wave's TS row tiles -> exchange area [row block wm][row tile][row fr] (rstd, -rstd * mean).  The four
+  // lanes fr, fr+16, fr+32, fr+48 hold the four k-quarters of a row.  E[x^2] - mean^2 in fp32 over one row (K <= 1280).
+  auto stats_publish = [&]() {
+    if constexpr (LNF) {
+      const float invk = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.f / (float)a.Ktot)));   // (an SGPR)
+#pragma unroll
+      for (int t = 0; t < TS; ++t) {
+        float sm = row_s[t], sq = row_q[t];
+        sm += __shfl_xor(sm, 16); sq += __shfl_xor(sq, 16);
+        sm += __shfl_xor(sm, 32); sq += __shfl_xor(sq, 32);
+        const float mean = sm * invk;
+        const float var = fmaxf(sq * invk - mean * mean, 0.f);
+        const float sc = rsqrtf(var + a.ln_eps);
+        if (fq == 0) *reinterpret_cast<float2*>(xch + XCH_STATS + (((wm * TM + wn * TS + t) * 16 + fr) << 3)) = float2{sc, -sc * mean};
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
   };
   // column constants of a tile: bias + (row vector of the tile's batch element, when the tile lies inside one)
   auto load_colconst = [&](int m0, int n0, f32x4 (&cb)[TN]) {
@@ -243,33 +314,91 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs_p, vo,
-                                                 ((row0 + i * 16) * a.N + n0 + wn * WTN + j * 16) * 4, 0);
+          store16(__builtin_bit_cast(u32x4, acc[i][j]), rs_p, vo, ((row0 + i * 16) * a.N + n0 + wn * WTN + j * 16) * 4);
       return;
     }
     __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)((size_t)a.M * a.ldo * 2), 0x00020000);
-    const int vo16 = (fr * a.ldo + pair_col) * 2, vo8 = (fr * a.ldo + fq * 4) * 2;
+    // (LNF is out of registers: its per-lane epilogue offsets are re-derived here from an opaque copy of the lane id so that
+    //  they are not hoisted out of the tile loop -- a hoisted value gets spilled, and a scratch reload inside the slab loop
+    //  comes with a vmcnt(0) that drains the DMA stream)
+    int vo16, vo8, efr = fr, efq = fq;
+    if constexpr (LNF) {
+      const int el = fresh_lane();
+      efr = el & 15; efq = el >> 4;
+      vo16 = (efr * a.ldo + (efq & 1) * 16 + (efq >> 1) * 8) * 2; vo8 = (efr * a.ldo + efq * 4) * 2;
+    } else {
+      vo16 = (fr * a.ldo + pair_col) * 2; vo8 = (fr * a.ldo + fq * 4) * 2;
+    }
     if constexpr (GEGLU) {
       // column tiles (j, j+1) = (value, gate) of ONE 16-wide output tile; output tiles are then paired for 16-byte stores
       constexpr int NO = TN / 2;                           // output column tiles per wave
       const int oc0 = (n0 + wn * WTN) / 2;
-      f32x4 cb[TN];
-      load_colconst(m0, n0, cb);
+      auto gate = [&](const f32x4& v, const f32x4& g) -> u32x2 {
+        return u32x2{pack2bf(v[0] * gelu_erf_f(g[0]), v[1] * gelu_erf_f(g[1])), pack2bf(v[2] * gelu_erf_f(g[2]), v[3] * gelu_erf_f(g[3]))};
+      };
+      if constexpr (LNF) {
+        // same store order as the plain form; the (c1, c2) of a column tile are read from the exchange area at every use
+        // (2 x TN x 4 registers for them do not exist next to 160 accumulators; the LDS is idle in this phase)
+        const unsigned char* cc = xch + (wn * WTN + efq * 4) * 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const float2 st = *reinterpret_cast<const float2*>(xch + XCH_STATS + (((wm * TM + i) * 16 + efr) << 3));
+          auto lin = [&](int j) -> f32x4 {
+            return acc[i][j] * st.x + (*reinterpret_cast<const f32x4*>(cc + XCH_C1 + j * 64) * st.y + *reinterpret_cast<const f32x4*>(cc + XCH_C2 + j * 64));
+          };
+          u32x2 o[NO];
+#pragma unroll
+          for (int q = 0; q < NO; ++q) o[q] = gate(lin(2 * q), lin(2 * q + 1));
+          const int so = ((row0 + i * 16) * a.ldo + oc0) * 2;
+#pragma unroll
+          for (int q = 0; q + 1 < NO; q += 2) {
+            swap_pair(o[q], o[q + 1]);
+            store16(u32x4{o[q][0], o[q][1], o[q + 1][0], o[q + 1][1]}, rs_o, vo16, so + q * 32);
+          }
+          if (NO & 1) __builtin_amdgcn_raw_buffer_store_b64(o[NO - 1], rs_o, vo8, so + (NO - 1) * 32, 0);
+        }
+      } else {
+        f32x4 cb[TN];
+        load_colconst(m0, n0, cb);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          u32x2 o[NO];
+#pragma unroll
+          for (int q = 0; q < NO; ++q) o[q] = gate(acc[i][2 * q] + cb[2 * q], acc[i][2 * q + 1] + cb[2 * q + 1]);
+          const int so = ((row0 + i * 16) * a.ldo + oc0) * 2;
+#pragma unroll
+          for (int q = 0; q + 1 < NO; q += 2) {
+            swap_pair(o[q], o[q + 1]);
+            store16(u32x4{o[q][0], o[q][1], o[q + 1][0], o[q + 1][1]}, rs_o, vo16, so + q * 32);
+          }
+          if (NO & 1) __builtin_amdgcn_raw_buffer_store_b64(o[NO - 1], rs_o, vo8, so + (NO - 1) * 32, 0);
+        }
+      }
+    } else if constexpr (LNF) {
+      // no residual / row vector in this form.  Same store order as the plain epilogue (a row tile's 160 bytes per row go out
+      // back to back); the tile's column constants come from the exchange area once per epilogue.
+      const unsigned char* cc = xch + (wn * WTN + efq * 4) * 4;
+      f32x4 k1[TN], k2[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        k1[j] = *reinterpret_cast<const f32x4*>(cc + XCH_C1 + j * 64);
+        k2[j] = *reinterpret_cast<const f32x4*>(cc + XCH_C2 + j * 64);
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        u32x2 o[NO];
+        const float2 st = *reinterpret_cast<const float2*>(xch + XCH_STATS + (((wm * TM + i) * 16 + efr) << 3));
+        const int so = ((row0 + i * 16) * a.ldo + n0 + wn * WTN) * 2;
+        auto one = [&](int j) -> u32x2 {
+          const f32x4 v = (acc[i][j] * st.x + (k1[j] * st.y + k2[j])) * alpha;
+          return u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+        };
 #pragma unroll
-        for (int q = 0; q < NO; ++q) {
-          const f32x4 v = acc[i][2 * q] + cb[2 * q], g = acc[i][2 * q + 1] + cb[2 * q + 1];
-          o[q] = u32x2{pack2bf(v[0] * gelu_erf_f(g[0]), v[1] * gelu_erf_f(g[1])), pack2bf(v[2] * gelu_erf_f(g[2]), v[3] * gelu_erf_f(g[3]))};
+        for (int j = 0; j + 1 < TN; j += 2) {
+          u32x2 oa = one(j), ob = one(j + 1);
+          swap_pair(oa, ob);
+          store16(u32x4{oa[0], oa[1], ob[0], ob[1]}, rs_o, vo16, so + j * 32);
         }
-        const int so = ((row0 + i * 16) * a.ldo + oc0) * 2;
-#pragma unroll
-        for (int q = 0; q + 1 < NO; q += 2) {
-          swap_pair(o[q], o[q + 1]);
-          __builtin_amdgcn_raw_buffer_store_b128(u32x4{o[q][0], o[q][1], o[q + 1][0], o[q + 1][1]}, rs_o, vo16, so + q * 32, 0);
-        }
-        if (NO & 1) __builtin_amdgcn_raw_buffer_store_b64(o[NO - 1], rs_o, vo8, so + (NO - 1) * 32, 0);
+        if (TN & 1) __builtin_amdgcn_raw_buffer_store_b64(one(TN - 1), rs_o, vo8, so + (TN - 1) * 32, 0);
       }
     } else {
       const bool has_res = a.res != nullptr;
@@ -318,7 +447,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
             }
             u32x2 oa = finish(acc[i][2 * q], 2 * q, ra), ob = finish(acc[i][2 * q + 1], 2 * q + 1, rb);
             swap_pair(oa, ob);
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{oa[0], oa[1], ob[0], ob[1]}, rs_o, vo16, so + q * 64, 0);
+            store16(u32x4{oa[0], oa[1], ob[0], ob[1]}, rs_o, vo16, so + q * 64);
           }
           if (TN & 1) __builtin_amdgcn_raw_buffer_store_b64(finish(acc[i][TN - 1], TN - 1, has_res ? rs1[g] : u32x2{0u, 0u}), rs_o, vo8, so + (TN - 1) * 32, 0);
         }
@@ -338,6 +467,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
   // byte offset per half slab (the halves differ by chunk bit 2 = 64 bytes), the row tile is an immediate offset and the
   // stage / wave position is scalar.
   bf16x8 af[TM], wf[TN];
+  u32x4 sf[LNF ? TS : 1];      // LNF: a second copy of the A fragments of the wave's own statistics row tiles (wn * TS + t)
   const int frag_off = fr * 128 + ((fq ^ ((fr >> 1) & 7)) << 4);
   auto read_frags = [&](int st, int half) {
     const unsigned char* sa = smem + st * STAGE_BYTES + wm * (WTM * 128) + (frag_off ^ (half * 64));
@@ -346,6 +476,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
     for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sb + j * 2048);
 #pragma unroll
     for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + i * 2048);
+    if constexpr (LNF) {   // (a scalar offset picks the tiles: cheaper than selecting them out of af[] with 3 v_cndmask per dword)
+#pragma unroll
+      for (int t = 0; t < TS; ++t) sf[t] = *reinterpret_cast<const u32x4*>(sa + (wn * TS + t) * 2048);
+    }
   };
   auto mfma_half = [&]() {
     __builtin_amdgcn_s_setprio(1);
@@ -354,6 +488,22 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
 #pragma unroll
       for (int j = 0; j < TN; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    if constexpr (LNF) {
+      // 8 * TS dot products, independent of the MFMAs: they issue in the shadow of the matrix pipe
+      typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+      const bf16x2 ones = __builtin_bit_cast(bf16x2, 0x3f803f80u);
+#pragma unroll
+      for (int t = 0; t < TS; ++t) {
+        const unsigned d[4] = {sf[t].x, sf[t].y, sf[t].z, sf[t].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bf16x2 x = __builtin_bit_cast(bf16x2, d[e]);
+          row_q[t] = __builtin_amdgcn_fdot2_f32_bf16(x, x, row_q[t], false);
+          row_s[t] = __builtin_amdgcn_fdot2_f32_bf16(x, ones, row_s[t], false);
+        }
+        asm volatile("" : "+v"(row_q[t]), "+v"(row_s[t]));   // pinned to this phase (hipcc otherwise sinks both halves' sums behind M1)
+      }
+    }
     __builtin_amdgcn_s_setprio(0);
   };
   // phase boundary: nothing moves across it at compile time; the barrier itself is the raw s_barrier (no implied
@@ -383,6 +533,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
   setup_loader(tile);
   issue_a(0, kt0);
   if (grp == 0) issue_w(0, kt0, 0, W_Q);
+  issue_consts(ld_n0);
   init_acc();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   phase_end();
@@ -411,6 +562,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
       const int nlk = last_k ? nkt0 : kt + 1;          // the slab being fetched
       if (pend) {                                      // ---- E: both groups' epilogues in one common phase
         if (grp == 0) phase_end();                     //   group 0 idles through group 1's last M1 ...
+        if constexpr (LNF) { stats_publish(); phase_end(); }
         epilogue(pm0, pn0, pks);
         init_acc();
         phase_end();
@@ -418,6 +570,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
         pend = false;
       }
       // ---- R0
+      if (LNF && kt == kt0 && tile != tstart + xj) issue_consts(n0);   // (the first tile's were issued by the prologue)
       read_frags(cur, 0);
       if (more) {
         if (last_k) setup_loader(next_tile);           // the loader runs ahead into the next work item
@@ -448,16 +601,19 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
     if (!have_next) break;
     tile = next_tile; kt0 = nkt0; kt1 = nkt1;
   }
-  epilogue(pm0, pn0, pks);               // the last work item's
+  // the last work item's.  (LNF: statistics are traded inside a group -- a wave's row block wm determines its group -- so
+  // it does not matter that group 1 is still in its last M1 when group 0 publishes.)
+  if constexpr (LNF) { stats_publish(); phase_end(); }
+  epilogue(pm0, pn0, pks);
   if (grp == 0) phase_end();             // balance the extra barrier group 1 executed up front
 }
 
-template <int BM, int WM, int WN, int AMODE, bool SPLITK>
+template <int BM, int WM, int WN, int AMODE, bool SPLITK, bool LNF = false>
 int launch_pp(const MvdGemmArgs& a, hipStream_t s) {
-  constexpr int LDS_BYTES = 2 * (BM * 128 + B_BYTES);
+  constexpr int LDS_BYTES = 2 * (BM * 128 + B_BYTES) + (LNF ? XCH_BYTES : 0);
   static bool init = false;
   if (!init) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<BM, WM, WN, AMODE, SPLITK>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<BM, WM, WN, AMODE, SPLITK, LNF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) { mvd_set_error("gemm_pp: hipFuncSetAttribute: %s", hipGetErrorString(e)); return -2; }
     init = true;
@@ -467,7 +623,7 @@ int launch_pp(const MvdGemmArgs& a, hipStream_t s) {
   const int ntiles = ntm * ntn * (a.splitk > 1 ? a.splitk : 1);
   if (ntiles < grid) grid = ((ntiles + 7) / 8) * 8;
   g_mvd_last_gemm.tiles = ntiles; g_mvd_last_gemm.grid = grid; g_mvd_last_gemm.per_cu = 1;
-  hipLaunchKernelGGL((gemm_pp_kernel<BM, WM, WN, AMODE, SPLITK>), dim3(grid), dim3(NT), LDS_BYTES, s, a);
+  hipLaunchKernelGGL((gemm_pp_kernel<BM, WM, WN, AMODE, SPLITK, LNF>), dim3(grid), dim3(NT), LDS_BYTES, s, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { mvd_set_error("gemm_pp launch: %s", hipGetErrorString(e)); return -3; }
   return 0;
@@ -512,9 +668,28 @@ bool mvd_gemm_pp_applicable(const MvdGemmArgs& a) {
 // (A 128-row instantiation of the same kernel -- BM = 128, wave tile 64 x 80, for the 16x16 / 8x8 levels -- was measured
 //  against the 128x160 lock-step tiles those levels use: no faster, profiles/r02_probe_pp128.log; not instantiated.)
 int mvd_launch_gemm_pp(const MvdGemmArgs& a, hipStream_t s) {
+  if (a.ln_c1) {
+    const MvdASeg& g = a.seg[0];
+    if (a.nseg != 1 || g.mode != MVD_A_DENSE || g.c1 || a.splitk > 1 || a.res || a.rowvec || !a.bias) {
+      mvd_set_error("gemm_pp: the LayerNorm fold takes one dense source, a bias, no residual / row vector / split-K"); return -1;
+    }
+    return a.geglu ? launch_pp<256, 4, 2, 0, false, true>(a, s) : launch_pp<256, 2, 4, 0, false, true>(a, s);
+  }
   if (a.geglu) {
     if (a.seg[0].mode != MVD_A_DENSE || a.splitk > 1) { mvd_set_error("gemm_pp: GEGLU needs a dense, unsplit problem"); return -1; }
     return launch_pp<256, 4, 2, 0, false>(a, s);
   }
   return launch_pp_mode<256, 2, 4>(a, s);
+}
+
+bool mvd_gemm_ln_fold_ok(const MvdGemmArgs& a) {
+  const MvdASeg& g = a.seg[0];
+  if (a.nseg != 1 || g.mode != MVD_A_DENSE || g.c1 || a.splitk > 1 || a.res || a.rowvec || a.out_f32) return false;
+  if (a.Ktot != g.c0 || a.Ktot > 1280) return false;
+  // measured (tools/probe_lnfold.py, profiles/r02_probe_lnfold.log): the fold saves 36-47 us per launch at C = 320 and 5-19 us
+  // at C = 640 -- except for the GEGLU form at C = 640, which loses 9 us (its epilogue fetches the column constants from LDS
+  // at every use): that one keeps ln_kernel + the plain kernel
+  if (a.geglu && a.Ktot > 320) return false;
+  const int cfg = mvd_gemm_pick_config(a);
+  return (a.geglu ? cfg == 6 : cfg == 7) && mvd_gemm_pp_applicable(a);
 }

@@ -44,15 +44,25 @@ struct MvdGemmArgs {
   int splitk;             // > 1: K is split over `splitk` work items per tile; raw fp32 partial tiles go to `part`
   float* part;            // [splitk][M][N] fp32 partials (then mvd_launch_splitk_reduce applies the epilogue)
   int dbg;                // probe builds only (-DMVD_PROBE, env MVD_GEMM_DEBUG): bit0 skip the output stores, bit1 skip the MFMAs
+  // LayerNorm fold (ping-pong kernels only, see mvd_gemm_ln_fold_ok): A holds the UN-normalised rows x, W holds
+  // W.diag(gamma), ln_c1[n] = sum_k W[n][k] (of the bf16 values), bias[n] = sum_k beta[k].W0[n][k] + b[n]; the kernel
+  // accumulates the row sums / sums of squares of the A fragments it multiplies and its epilogue applies
+  //   out = rstd[m] * (acc - mean[m] * ln_c1[n]) + bias[n]      ( = LayerNorm(x).W0^T + b )
+  const float* ln_c1;     // [N] fp32 or null
+  float ln_eps;
 };
 
 int mvd_launch_gemm(const MvdGemmArgs& a, hipStream_t s, int force_cfg = -1);
+int mvd_gemm_pick_config(const MvdGemmArgs& a);   // tile config the heuristic gives this problem
 // what the calling thread's last mvd_launch_gemm launched (tests assert that the persistent multi-tile path ran)
 struct MvdLaunchPlan { int cfg, splitk, tiles, grid, per_cu; };
 extern thread_local MvdLaunchPlan g_mvd_last_gemm;
 // 256x320 "ping-pong" kernels (gemm_pp.hip): buffer-addressed LDS-DMA, two wave groups one phase apart.  Used for tile
 // configs 6 (GEGLU) and 7 whenever every byte offset fits 32-bit buffer addressing; arguments validated by mvd_launch_gemm.
 bool mvd_gemm_pp_applicable(const MvdGemmArgs& a);
+// true when a problem with a.ln_c1 set can run (one dense source spanning the whole row, no residual / row vector /
+// split-K, and a shape the heuristic gives to the ping-pong kernels); the engine falls back to ln_kernel + plain GEMM otherwise
+bool mvd_gemm_ln_fold_ok(const MvdGemmArgs& a);
 int mvd_launch_gemm_pp(const MvdGemmArgs& a, hipStream_t s);
 // ring-pipelined 256x320 experiment (gemm_ring.hip, linked into probe builds only); arguments already validated by mvd_launch_gemm
 int mvd_launch_gemm_ring(const MvdGemmArgs& a, hipStream_t s);

@@ -47,6 +47,17 @@ def linear(a, w, bias=None, a2=None, rowvec=None, rows_per_batch=0, res=None, al
     return out
 
 
+def ln_linear(x, w_folded, cf, eps=1e-5, geglu=False):
+    """LayerNorm(x).W^T + b (optionally GEGLU) in one kernel; (w_folded, cf) from packing.fold_layernorm."""
+    _bf16(x, w_folded)
+    m, k = x.shape
+    n = w_folded.shape[0]
+    assert w_folded.shape[1] == k and cf.shape == (2, n) and cf.dtype == torch.float32 and cf.is_contiguous()
+    out = torch.empty(m, n // 2 if geglu else n, device=x.device, dtype=torch.bfloat16)
+    L.call("mvd_op_ln_linear", _p(x), k, _p(w_folded), _p(cf[0]), _p(cf[1]), float(eps), int(geglu), _p(out), m, n, _s())
+    return out
+
+
 def conv3x3(x, w_packed, bias=None, stride=1, upsample=False, rowvec=None, res=None, shortcut=None,
             shortcut2=None, force_cfg=-1, splitk=1, asym_pad=False):
     """x: (B,H,W,Cin) bf16; w_packed: (Cout, 9*Cin [+ Csc]) bf16 tap-major.  asym_pad (stride 2): zero padding on the

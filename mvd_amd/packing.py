@@ -11,6 +11,8 @@ One-time host work (torch is used as plumbing for the permutes / casts).  Slot l
   ref_kv        [to_k_ref(self); to_v_ref(self); to_k_ref(cross); to_v_ref(cross)]
   ff1           GEGLU rows interleaved in blocks of 16: (16 value rows, 16 gate rows)
   temb_proj     every resnet's time_emb_proj stacked in module order (one GEMM per forward)
+  <slot>.wf/.cf LayerNorm-folded twins of attn1.qkv / attn2.q / ff1 (fold_layernorm): the fused LayerNorm GEMM reads the
+                un-normalised rows; packed for C <= LN_FOLD_MAX_C (the levels whose GEMMs are big enough for that kernel)
 """
 from __future__ import annotations
 
@@ -51,6 +53,23 @@ def _geglu_rows(w: torch.Tensor) -> torch.Tensor:
     v = val.reshape(half // 16, 1, 16, *rest)
     g = gate.reshape(half // 16, 1, 16, *rest)
     return torch.cat([v, g], dim=1).reshape(w.shape)
+
+
+# LayerNorm fold: only the 64x64 / 32x32 levels (C = 320 / 640 in SD-2.1) ever reach the fused kernel (it needs >= 200
+# tiles of 256x320, i.e. many rows); deeper levels keep ln_kernel + the plain GEMM and get no folded twin
+LN_FOLD_MAX_C = 640
+
+
+def fold_layernorm(w: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, bias, device):
+    """LayerNorm(x).W^T + b  ==  rstd*(x.Wf^T - mean*c1) + c2  with  Wf = W.diag(gamma) (bf16), c1 = Wf.1 (summed over the
+    bf16 values, so that the mean term cancels exactly what the GEMM accumulated), c2 = W.beta + b.  Returns (wf, cf[2][N])."""
+    w, gamma, beta = w.detach().float(), gamma.detach().float(), beta.detach().float()
+    wf = (w * gamma[None, :]).to(torch.bfloat16)
+    c1 = wf.float().sum(1)
+    c2 = w @ beta
+    if bias is not None:
+        c2 = c2 + bias.detach().float()
+    return wf.to(device).contiguous(), torch.stack([c1, c2], 0).to(device=device, dtype=torch.float32).contiguous()
 
 
 def pack_unet(sd: Dict[str, torch.Tensor], cfg: UNetConfig, device, adapter: bool, ref_scale: float = 0.0) -> Dict[str, torch.Tensor]:
@@ -119,8 +138,13 @@ def pack_unet(sd: Dict[str, torch.Tensor], cfg: UNetConfig, device, adapter: boo
         out[f"{key}.attn1.qkv.w"] = _bf(torch.cat(qkv, 0), device)
         out[f"{key}.attn2.q.w"] = _bf(torch.cat(q2, 0), device)
         tkv.append(torch.cat([f(f"{b}.attn2.to_k.weight"), f(f"{b}.attn2.to_v.weight")], 0))
-        out[f"{key}.ff1.w"] = _bf(_geglu_rows(f(f"{b}.ff.net.0.proj.weight")), device)
-        out[f"{key}.ff1.b"] = _f32(_geglu_rows(f(f"{b}.ff.net.0.proj.bias")), device)
+        ff1_w, ff1_b = _geglu_rows(f(f"{b}.ff.net.0.proj.weight")), _geglu_rows(f(f"{b}.ff.net.0.proj.bias"))
+        out[f"{key}.ff1.w"] = _bf(ff1_w, device)
+        out[f"{key}.ff1.b"] = _f32(ff1_b, device)
+        if C <= LN_FOLD_MAX_C:
+            for slot, w, bias, i in ((f"{key}.attn1.qkv", torch.cat(qkv, 0), None, 1), (f"{key}.attn2.q", torch.cat(q2, 0), None, 2),
+                                     (f"{key}.ff1", ff1_w, ff1_b, 3)):
+                out[f"{slot}.wf"], out[f"{slot}.cf"] = fold_layernorm(w, f(f"{b}.norm{i}.weight"), f(f"{b}.norm{i}.bias"), bias, device)
         out[f"{key}.ff2.w"] = _bf(sd[f"{b}.ff.net.2.weight"], device)
         out[f"{key}.ff2.b"] = _f32(sd[f"{b}.ff.net.2.bias"], device)
 

@@ -279,6 +279,49 @@ def test_layernorm_cfg4_shapes(ops, rows, c):
     close(ops.layernorm(x, g, b), F.layer_norm(x.float(), (c,), g, b, 1e-5), tol=2 ** -6, what=f"layernorm {rows}x{c}")
 
 
+# ------------------------------------------------------------------------------- LayerNorm folded into the GEMM (64^2 / 32^2 levels)
+@pytest.mark.parametrize("m,c,nmul,geglu,offset", [
+    (131072, 320, 4, False, 0.3),     # ln1 -> [q; k; v; q_ref]
+    (131072, 320, 1, False, 0.3),     # ln2 -> q (no adapter)
+    (32768, 640, 4, False, 0.3),
+    (32768, 640, 2, False, 8.0),      # rows with |mean| = 8 std: the E[x^2] - mean^2 form must hold up
+    (131072, 320, 8, True, -2.0),     # ln3 -> ff1 + GEGLU (the C = 640 GEGLU keeps the separate LayerNorm: measured slower fused)
+])
+def test_layernorm_fold_cfg4_shapes(ops, m, c, nmul, geglu, offset):
+    """LayerNorm(x).W^T + b as ONE kernel (gemm_pp_kernel<..., LNF>: statistics from the MFMA fragments, gamma folded into W,
+    epilogue rstd*(acc - mean*c1) + c2) against fp32 layer_norm + matmul on the same bf16 x and the UNfolded fp32 weights."""
+    from mvd_amd.packing import _geglu_rows, fold_layernorm
+    n = nmul * c
+    x = grnd(m, c, scale=1.3, seed=101) + offset
+    x[:7] *= 0.01                                      # a few low-variance rows (rstd ~ 1e2)
+    w = grnd(n, c, scale=1 / math.sqrt(c), seed=102).float()
+    gamma = 1.0 + 0.3 * grnd(c, seed=103, dtype=torch.float32)
+    beta = 0.2 * grnd(c, seed=104, dtype=torch.float32)
+    bias = grnd(n, seed=105, dtype=torch.float32) if geglu else None
+    h = F.layer_norm(x.float(), (c,), gamma, beta, 1e-5) @ w.T
+    if geglu:
+        h = h + bias
+        want = h[:, : n // 2] * F.gelu(h[:, n // 2:])
+        wf, cf = fold_layernorm(_geglu_rows(w), gamma, beta, _geglu_rows(bias), "cuda")
+    else:
+        want = h
+        wf, cf = fold_layernorm(w, gamma, beta, None, "cuda")
+    del h
+    got = ops.ln_linear(x, wf, cf, geglu=geglu)
+    _assert_persistent(ops, 6 if geglu else 7, f"ln-fold {m}x{n}x{c}", n=n, m=m)
+    close(got, want, tol=2 ** -6, what=f"ln-fold M={m} C={c} N={n} geglu={geglu}")
+
+
+def test_layernorm_fold_rejects_small_problems(ops):
+    """Shapes the fused kernel does not take (too few 256x320 tiles, N not a multiple of 320) are refused, not mis-run."""
+    from mvd_amd._lib import MvdError
+    from mvd_amd.packing import fold_layernorm
+    for m, c, n in [(2048, 1280, 1280), (131072, 320, 384)]:          # too few tiles; N % 320 != 0
+        wf, cf = fold_layernorm(grnd(n, c).float(), torch.ones(c, device="cuda"), torch.zeros(c, device="cuda"), None, "cuda")
+        with pytest.raises(MvdError):
+            ops.ln_linear(grnd(m, c), wf, cf)
+
+
 # ------------------------------------------------------------------------------- the whole forward at B = 32
 def test_sd21_full_size_parity_b32():
     """configs[3] end to end: 32 pairs, full SD-2.1 shapes, camera FiLM + cross-view adapter, cold forward, vs the CPU

@@ -11,7 +11,7 @@ def rnd(*s, scale=1.0): return (torch.randn(*s, device="cuda") * scale).to(torch
 def p(t): return C.c_void_p(t.data_ptr()) if t is not None else None
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
-for (m, n, k, res) in [(131072, 1280, 320, 0), (131072, 320, 320, 1), (131072, 320, 1280, 1), (32768, 640, 2560, 1)]:
+for (m, n, k, res) in [(131072, 1280, 320, 0), (131072, 320, 320, 1), (131072, 320, 320, 0), (32768, 640, 1280, 1)]:
     a, w, b = rnd(m, k), rnd(n, k, scale=1 / math.sqrt(k)), torch.randn(n, device="cuda")
     r = rnd(m, n) if res else None
     out = torch.empty(m, n, device="cuda", dtype=torch.bfloat16)
@@ -24,18 +24,21 @@ for (m, n, k, res) in [(131072, 1280, 320, 0), (131072, 320, 320, 1), (131072, 3
     print(f"== dense M={m} N={n} K={k} res={res}: {nslab} slabs x 4 phases per tile")
     for g in (0, 1):
         work, wait = {}, {}
+        per = 4 * nslab + 2                      # phases per tile after the first: (idle, E | E, idle) + 4 per slab
         for wg in range(64):
             cnt = int(s[wg, g, 0])
             v = s[wg, g, 1:1 + cnt].tolist()
             # stamps alternate (arrive, release); skip the prologue barriers (1 for group 0, 2 for group 1)
             pairs = [(v[i], v[i + 1]) for i in range(0, cnt - 1, 2)]
             pairs = pairs[(1 if g == 0 else 2):]
-            for i in range(1, len(pairs)):
-                ph = (i) % (4 * nslab)               # phase index within a tile (0 = R0 of slab 0)
+            for i in range(4 * nslab + 1, len(pairs)):    # from the second tile on (the first has no E phase)
+                ph = (i - 4 * nslab) % per
                 work.setdefault(ph, []).append(pairs[i][0] - pairs[i - 1][1])
                 wait.setdefault(ph, []).append(pairs[i][1] - pairs[i][0])
-        names = ["R0", "M0", "R1", "M1"]
+        head = ["idle", "E"] if g == 0 else ["E", "idle"]
+        names = head + [f"{n}{k}" for k in range(nslab) for n in ("R0.", "M0.", "R1.", "M1.")]
         line = []
         for ph in sorted(work):
-            line.append(f"{names[ph % 4]}{ph // 4}:{statistics.median(work[ph]):.0f}+{statistics.median(wait[ph]):.0f}")
-        print(f"  group {g} (work+wait cycles): " + " ".join(line))
+            line.append(f"{names[ph]}:{statistics.median(work[ph]):.0f}+{statistics.median(wait[ph]):.0f}")
+        tot = sum(statistics.median(work[ph]) + statistics.median(wait[ph]) for ph in work)
+        print(f"  group {g} (work+wait cycles, {tot:.0f} per tile): " + " ".join(line))
