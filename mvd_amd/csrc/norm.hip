@@ -161,6 +161,148 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
   }
 }
 
+// ---------------------------------------------------------------- GroupNorm in ONE pass (register-resident slice)
+// A workgroup owns `gpw` consecutive groups of ONE image -- a channel slice of cs = gpw * C/groups channels (a multiple of
+// 8) over all hw pixels -- and keeps it in registers (NV 16-byte vectors per thread): read once, exact two-pass statistics
+// (mean, then sum (x - mean)^2: no cancellation, no shift), normalise + affine (+SiLU), write once.  Two trips over HBM
+// instead of the three of gn_stats + gn_apply, and one launch instead of two (the 16x16 / 8x8 levels and batch 1 are
+// launch-latency bound).  Thread t handles vector v = t % nvec of pixels t / nvec, t / nvec + npl, ...: its 8 channels
+// stay fixed, so its affine constants live in registers and its elements fall into at most two groups (cg >= 8, even).
+// Reductions are fixed-order (per-thread partials -> LDS -> one wave per group, xor-shuffle tree): bit-deterministic.
+// Slices of one image sit on one XCD (blockIdx & 7 = image & 7 when the batch allows) so that the 128-byte lines they
+// share are fetched / written back once by that XCD's L2.
+template <int NV>
+__global__ __launch_bounds__(1024) void gn_slice_kernel(const bf16_t* __restrict__ x0, const bf16_t* __restrict__ x1,
+                                                         int c0, int c1, int batch, int hw, int groups, int gpw, float eps,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         int silu, bf16_t* __restrict__ y) {
+  __shared__ float2 part[1024];
+  __shared__ int glo_of[1024];
+  __shared__ float s_mean[32], s_rstd[32];
+  const int C = c0 + c1, cg = C / groups, cs = gpw * cg, nvec = cs >> 3, nslice = groups / gpw;
+  const int nthr = blockDim.x, npl = nthr / nvec;
+  int b, slice;
+  if ((batch & 7) == 0) { const int r = blockIdx.x >> 3; slice = r % nslice; b = (r / nslice) * 8 + (blockIdx.x & 7); }
+  else { b = blockIdx.x / nslice; slice = blockIdx.x - b * nslice; }
+  const int t = threadIdx.x;
+  const int pl = t / nvec, v = t - pl * nvec;
+  const bool active = pl < npl;
+  const int ch = slice * cs + v * 8;                       // first channel of the thread's vector
+  const int glo = (v * 8) / cg;                            // slice-local group of element 0
+  const int kb = (glo + 1) * cg - v * 8;                   // elements j >= kb belong to group glo + 1 (kb >= 8: none)
+  glo_of[t] = active ? glo : -4;
+
+  // Buffer addressing: one descriptor per source image, a loop-invariant per-thread byte offset, the pixel step as a
+  // scalar offset -- no per-vector 64-bit addresses (they would double the registers a vector costs).  Pixels >= hw and the
+  // threads beyond npl * nvec fall outside num_records: their loads return zeros, their stores are dropped.
+  constexpr unsigned OOB = 0x80000000u;
+  __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(x0 + (size_t)b * hw * c0), 0, hw * c0 * 2, 0x00020000);
+  const unsigned vo0 = active && ch < c0 ? (unsigned)(pl * c0 + ch) * 2u : OOB;
+  const int st0 = npl * c0 * 2;                           // (scalar) byte step between a thread's consecutive pixels
+  u32x4 d[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) d[i] = __builtin_amdgcn_raw_buffer_load_b128(rs0, vo0, i * st0, 0);
+  if (c1 && ch >= c0) {      // threads whose channels lie in the second source: same registers, loads under their exec mask
+    __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(x1 + (size_t)b * hw * c1), 0, hw * c1 * 2, 0x00020000);
+    const unsigned vo1 = active ? (unsigned)(pl * c1 + ch - c0) * 2u : OOB;
+    const int st1 = npl * c1 * 2;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) d[i] = __builtin_amdgcn_raw_buffer_load_b128(rs1, vo1, i * st1, 0);
+  }
+  const int nval = active && pl < hw ? (hw - pl + npl - 1) / npl : 0;          // the thread's valid vectors are d[0 .. nval)
+  const float inv_n = 1.f / ((float)hw * (float)cg);
+  // fixed-order reduction of the per-thread (slot 0, slot 1) partials into one value per group
+  auto reduce_groups = [&](float p0, float p1, float* out, bool to_rstd) {
+    part[t] = float2{p0, p1};
+    __syncthreads();
+    const int wave = t >> 6, lane = t & 63, nwave = nthr >> 6;
+    for (int g = wave; g < gpw; g += nwave) {
+      float a = 0.f;
+      for (int q = lane; q < nthr; q += 64) {
+        const int gl = glo_of[q];
+        const float2 pq = part[q];
+        a += gl == g ? pq.x : 0.f;
+        a += gl + 1 == g ? pq.y : 0.f;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+      if (lane == 0) out[g] = to_rstd ? rsqrtf(a * inv_n + eps) : a * inv_n;
+    }
+    __syncthreads();
+  };
+  // The 8 channels of a vector are 4 dwords (channel pairs); cg is even, so a pair never straddles a group: dword w belongs
+  // to slot 0 (group glo) iff 2w < kb.  Both passes keep one accumulator per dword and sort them into slots at the end --
+  // no per-element select in the loops.
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  const bf16x2_t ones = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
+  // ---- pass A: mean (v_dot2c_f32_bf16 with (1, 1) sums a pair straight from the packed data; padding vectors are zeros)
+  float pa[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const unsigned w[4] = {d[i].x, d[i].y, d[i].z, d[i].w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pa[k] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w[k]), ones, pa[k], false);
+  }
+  float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { if (2 * k < kb) a0 += pa[k]; else a1 += pa[k]; }
+  reduce_groups(a0, a1, s_mean, false);
+  const float m0 = s_mean[glo], m1 = s_mean[glo + 1 < gpw ? glo + 1 : glo];
+  // ---- pass B: sum of squared deviations
+  float mw[4], pq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) mw[k] = 2 * k < kb ? m0 : m1;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    if (i < nval) {
+      const unsigned w[4] = {d[i].x, d[i].y, d[i].z, d[i].w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float lo = bflo(w[k]) - mw[k], hi = bfhi(w[k]) - mw[k];
+        pq[k] = fmaf(lo, lo, pq[k]);
+        pq[k] = fmaf(hi, hi, pq[k]);
+      }
+    }
+  }
+  float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { if (2 * k < kb) q0 += pq[k]; else q1 += pq[k]; }
+  reduce_groups(q0, q1, s_rstd, true);
+  if (!active) return;
+  // ---- normalise + affine (+SiLU), store
+  float ga[8], gb[8];
+  {
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + ch), g1 = *reinterpret_cast<const f32x4*>(gamma + ch + 4);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + ch), b1 = *reinterpret_cast<const f32x4*>(beta + ch + 4);
+    const float r0 = s_rstd[glo], r1 = s_rstd[glo + 1 < gpw ? glo + 1 : glo];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float gm = j < 4 ? g0[j] : g1[j - 4], bt = j < 4 ? b0[j] : b1[j - 4];
+      ga[j] = gm * (j < kb ? r0 : r1);
+      gb[j] = bt - (j < kb ? m0 : m1) * ga[j];
+    }
+  }
+  __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(y + (size_t)b * hw * C, 0, hw * C * 2, 0x00020000);
+  const unsigned voy = (unsigned)(pl * C + ch) * 2u;
+  const int sty = npl * C * 2;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    if (i < nval) {
+      const unsigned w[4] = {d[i].x, d[i].y, d[i].z, d[i].w};
+      u32x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float lo = fmaf(bflo(w[k]), ga[2 * k], gb[2 * k]), hi = fmaf(bfhi(w[k]), ga[2 * k + 1], gb[2 * k + 1]);
+        if (silu) { lo = silu_f(lo); hi = silu_f(hi); }
+        o[k] = pack2bf(lo, hi);
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, voy, i * sty, 0);
+      asm volatile("s_nop 1" :: "v"(o));       // wait states hipcc leaves out behind a 16-byte store with an SGPR soffset (see gemm_pp.hip store16)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // ---------------------------------------------------------------- LayerNorm (bf16 rows)
 // one wave per row, row kept in registers (C <= 64*8*MAXV), two-pass mean/variance.
 template <int MAXV>
@@ -292,6 +434,35 @@ static int check_launch(const char* what) {
   return 0;
 }
 
+// One-pass form: applicable when a slice of gpw groups (the fewest whose channel count is a multiple of 8) of one image
+// fits the registers of one workgroup, and either the slices are small or there are enough of them to fill the chip.
+static bool launch_gn_slice(const bf16_t* x0, const bf16_t* x1, int c0, int c1, int batch, int hw, int groups, float eps,
+                            const float* gamma, const float* beta, int silu, bf16_t* y, hipStream_t s) {
+  static const int enable = MVD_ENV_INT("MVD_GN_SLICE", 1);
+  const int C = c0 + c1, cg = C / groups;
+  if (!enable || cg < 8 || (cg & 1)) return false;
+  int gpw = 1;
+  while (gpw <= groups && ((gpw * cg) % 8 || groups % gpw)) gpw <<= 1;
+  if (gpw > groups) return false;
+  const int cs = gpw * cg, nvec = cs / 8, nslice = groups / gpw;
+  // a source boundary inside a vector cannot happen (c0 % 8 == 0); inside a slice it can and is handled per vector
+  int threads = 1024, nv = 0;
+  for (int th : {256, 512, 1024}) {       // the smallest block that keeps <= 4 vectors per thread, else the largest
+    const int npl = th / nvec;
+    if (npl < 1) continue;
+    threads = th; nv = (hw + npl - 1) / npl;
+    if (nv <= 4) break;
+  }
+  if (nv < 1 || nv > 21) return false;
+  const long slice_bytes = (long)hw * cs * 2, nwg = (long)batch * nslice;
+  if (slice_bytes > 96 * 1024 && nwg < 128) return false;           // few big slices: the two-kernel form has more parallelism
+  const dim3 grid((unsigned)nwg), blk((unsigned)threads);
+#define GN_SLICE(NVT) hipLaunchKernelGGL(gn_slice_kernel<NVT>, grid, blk, 0, s, x0, x1, c0, c1, batch, hw, groups, gpw, eps, gamma, beta, silu, y)
+  if (nv <= 2) GN_SLICE(2); else if (nv <= 4) GN_SLICE(4); else if (nv <= 8) GN_SLICE(8); else if (nv <= 16) GN_SLICE(16); else GN_SLICE(21);
+#undef GN_SLICE
+  return true;
+}
+
 int mvd_launch_groupnorm(const bf16_t* x0, const bf16_t* x1, int c0, int c1, int batch, int hw, int groups, float eps,
                          const float* gamma, const float* beta, int silu, bf16_t* y, float* ws, hipStream_t s) {
   const int C = c0 + c1;
@@ -300,6 +471,7 @@ int mvd_launch_groupnorm(const bf16_t* x0, const bf16_t* x1, int c0, int c1, int
     mvd_set_error("groupnorm: bad arguments (c0=%d c1=%d batch=%d hw=%d groups=%d)", c0, c1, batch, hw, groups);
     return -1;
   }
+  if (launch_gn_slice(x0, x1, c0, c1, batch, hw, groups, eps, gamma, beta, silu, y, s)) return check_launch("gn_slice");
   const int vec = C / 8;
   if (vec > 1024) { mvd_set_error("groupnorm: C=%d too wide", C); return -1; }
   const int R = vec >= 256 ? 1 : 256 / vec;

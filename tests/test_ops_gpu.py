@@ -222,7 +222,10 @@ def test_attention_strided_views_and_spike(ops):
 
 
 # ------------------------------------------------------------------------------- norms
-@pytest.mark.parametrize("B,hw,c0,c1", [(2, 256, 320, 0), (1, 64, 1280, 640), (3, 16, 64, 64), (2, 4096, 64, 0), (1, 4, 1280, 1280)])
+@pytest.mark.parametrize("B,hw,c0,c1", [(2, 256, 320, 0), (1, 64, 1280, 640), (3, 16, 64, 64), (2, 4096, 64, 0), (1, 4, 1280, 1280),
+                                        # one-pass slice kernel: XCD-swizzled block order (batch % 8 == 0), a slice straddling the
+                                        # two sources, 16 / 21 vectors per thread, a ragged pixel count
+                                        (8, 1024, 640, 320), (16, 64, 1280, 0), (8, 4096, 320, 0), (3, 1000, 320, 320)])
 @pytest.mark.parametrize("silu", [False, True])
 def test_groupnorm(ops, B, hw, c0, c1, silu):
     x = rnd(B, hw, c0, seed=1, scale=2.0) + 0.5

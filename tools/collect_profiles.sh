@@ -10,16 +10,16 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 python bench.py --steps 20 --warmup 5 --shapes-out $OUT/shapes.txt > $OUT/bench_cfg4.json 2> $OUT/bench_cfg4.err
 cat $OUT/bench_cfg4.json
-rocprofv3 --kernel-trace --stats -d $OUT/prof -o stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-check > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
-cp $(ls $OUT/prof/*/stats_kernel_stats.csv $OUT/prof/stats_kernel_stats.csv 2>/dev/null | head -1) $OUT/kernel_stats.csv
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-check > /dev/null 2> $OUT/pmc_fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-check > /dev/null 2> $OUT/pmc_write.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-check > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
+cp $(find $OUT/prof -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats.csv
+rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-check > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-check > /dev/null 2> $OUT/pmc_write.err
 python tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_hbm_traffic.json > $OUT/pmc_hbm_traffic.txt
 # SQ counters on isolated launches of the hot kernels (tools/pmc_ops.py), a few counters per pass
 i=0
 for CS in "FETCH_SIZE" "WRITE_SIZE" "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" "SQ_INSTS_VMEM SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_WAVES"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $CS -d $OUT/pmc_sq$i -o s -- python3 tools/pmc_ops.py > /dev/null 2> $OUT/pmc_sq$i.err || echo "SQ pass $i failed (see pmc_sq$i.err)"
+  rocprofv3 --kernel-trace --output-format csv --pmc $CS -d $OUT/pmc_sq$i -o s -- python3 tools/pmc_ops.py > /dev/null 2> $OUT/pmc_sq$i.err || echo "SQ pass $i failed (see pmc_sq$i.err)"
 done
 python tools/pmc_ops_summary.py $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_sq3 $OUT/pmc_sq4 $OUT/pmc_sq5 > $OUT/pmc_sq_counters.txt || true
 rm -rf $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_sq3 $OUT/pmc_sq4 $OUT/pmc_sq5

@@ -23,8 +23,8 @@ def agg(path):
     return d
 
 def main(fetch_dir, write_dir, out):
-    f = agg(glob.glob(fetch_dir + "/*/*counter_collection.csv")[0])
-    w = agg(glob.glob(write_dir + "/*/*counter_collection.csv")[0])
+    f = agg(glob.glob(fetch_dir + "/**/*counter_collection.csv", recursive=True)[0])
+    w = agg(glob.glob(write_dir + "/**/*counter_collection.csv", recursive=True)[0])
     res = {}
     for cls, pat in CLASSES.items():
         n = sum(v[0] for k, v in f.items() if re.search(pat if pat.startswith('gemm_pp') else re.escape(pat), k))
