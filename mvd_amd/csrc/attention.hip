@@ -53,6 +53,25 @@ MVD_DEVINL float pair_sum(float x) { float o; const float p = pair_other(x, o); 
 // PRE: Q arrives pre-multiplied by softmax_scale * log2(e) (folded into the to_q weights by the host packing), so
 // the QK^T accumulator is already the exp2-domain score; it is STARTED at -running_max (C operand of the first
 // MFMA), so the exponent argument leaves the matrix pipe ready-made and the per-score v_fma disappears.
+// Workgroup -> (query block, head, batch * problem) on a 1-D grid, XCD aware: hardware deals consecutive workgroup ids
+// round-robin to the 8 XCDs, so with the plain (query block fastest) order the 32 query blocks of one (batch, head) -- which
+// all stream the SAME K/V -- land on 8 different L2s and every L2 fetches that K/V for itself (PMC: 0.8 GB of L2 fills per
+// launch on average).  Here XCD x works through the (batch, head) pairs x, x + 8, ...: all query blocks of a pair share one L2.
+MVD_DEVINL void attn_block(const MvdAttnArgs& a, int& qb, int& head, int& bz) {
+  const int npair = a.heads * a.batch * a.nprob;
+  const int nqb = gridDim.x / npair;
+  const int lid = blockIdx.x;
+  int pair;
+#ifdef MVD_ATTN_PLAIN_ORDER            // (A/B builds: tools/build_variant.py plain -DMVD_ATTN_PLAIN_ORDER)
+  if (false) {}
+#else
+  if ((npair & 7) == 0) { const int j = lid >> 3; qb = j % nqb; pair = (j / nqb) * 8 + (lid & 7); }
+#endif
+  else { qb = lid % nqb; pair = lid / nqb; }
+  head = pair % a.heads;
+  bz = pair / a.heads;
+}
+
 template <int NW, int NSUB, bool PRE>
 __global__ __launch_bounds__(64 * NW, (NW == 4 && NSUB == 2) ? 3 : 2) void attn_kernel(const MvdAttnArgs a) {
   constexpr int NT = 64 * NW;
@@ -65,13 +84,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && NSUB == 2) ? 3 : 2) void attn_
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 31, lh = lane >> 5;
-  const int head = blockIdx.y;
-  int bz = blockIdx.z;
+  int qb_, head, bz;
+  attn_block(a, qb_, head, bz);
   const int pi = bz / a.batch;
   bz -= pi * a.batch;
   const MvdAttnProblem& P = a.p[pi];
   const int nq = P.nq, nk = P.nk;
-  const int qblk0 = blockIdx.x * QB;
+  const int qblk0 = qb_ * QB;
   if (qblk0 >= nq) return;  // whole workgroup exits together (uniform)
 
   const bf16_t* qp = P.q + (size_t)bz * P.bsq + head * 64;
@@ -303,13 +322,13 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_pipe_kernel(const MvdAttnArgs
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 31, lh = lane >> 5;
-  const int head = blockIdx.y;
-  int bz = blockIdx.z;
+  int qb_, head, bz;
+  attn_block(a, qb_, head, bz);
   const int pi = bz / a.batch;
   bz -= pi * a.batch;
   const MvdAttnProblem& P = a.p[pi];
   const int nq = P.nq, nk = P.nk;
-  const int qblk0 = blockIdx.x * QB;
+  const int qblk0 = qb_ * QB;
   if (qblk0 >= nq) return;
 
   const bf16_t* qp = P.q + (size_t)bz * P.bsq + head * 64;
@@ -748,11 +767,11 @@ thread_local int g_last_attn[2] = {0, 0};
 template <int NW, int NSUB>
 int launch_nw(const MvdAttnArgs& a, int maxq, hipStream_t s) {
   const int qb = 32 * NW;
-  dim3 grid((maxq + qb - 1) / qb, a.heads, a.batch * a.nprob);
+  dim3 grid(((maxq + qb - 1) / qb) * a.heads * a.batch * a.nprob);      // 1-D: attn_block() decodes it
   // (the software-pipelined kernel is an experiment switch: at two waves per SIMD it measured 13 % SLOWER than the
   //  three-wave kernel above -- inter-wave overlap beats the intra-wave pipeline hipcc schedules; MVD_ATTN_PIPE=1)
   static const int pipe = MVD_ENV_INT("MVD_ATTN_PIPE", 0);
-  g_last_attn[0] = NW; g_last_attn[1] = (int)(grid.x * grid.y * grid.z);
+  g_last_attn[0] = NW; g_last_attn[1] = (int)grid.x;
   if (a.prescaled && NW == 4 && NSUB == 2 && pipe) hipLaunchKernelGGL((attn_pipe_kernel<4>), grid, dim3(256), 0, s, a);
   else if (a.prescaled) hipLaunchKernelGGL((attn_kernel<NW, NSUB, true>), grid, dim3(64 * NW), 0, s, a);
   else                  hipLaunchKernelGGL((attn_kernel<NW, NSUB, false>), grid, dim3(64 * NW), 0, s, a);

@@ -673,7 +673,7 @@ int mvd_launch_gemm(const MvdGemmArgs& a, hipStream_t s, int force_cfg) {
     case 4: return launch_cfg<C4>(a, s, glds);
     case 6:
       if (!a.geglu || a.seg[0].mode != MVD_A_DENSE || a.splitk > 1) { mvd_set_error("gemm: tile config 6 is GEGLU-only"); return -1; }
-      if (!legacy && !a.dbg && mvd_gemm_pp_applicable(a)) return mvd_launch_gemm_pp(a, s);
+      if (!legacy && !(a.dbg & ~32) && mvd_gemm_pp_applicable(a)) return mvd_launch_gemm_pp(a, s);
       return launch_mode2<C6, 0, true, false>(a, s);
     case 7:
       if (!legacy && !(a.dbg & ~32) && !a.geglu && mvd_gemm_pp_applicable(a)) return mvd_launch_gemm_pp(a, s);

@@ -11,13 +11,14 @@ def rnd(*s, scale=1.0): return (torch.randn(*s, device="cuda") * scale).to(torch
 def p(t): return C.c_void_p(t.data_ptr()) if t is not None else None
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
-for (m, n, k, res) in [(131072, 1280, 320, 0), (131072, 320, 320, 1), (131072, 320, 320, 0), (32768, 640, 1280, 1)]:
+for (m, n, k, res) in [(131072, 1280, 320, 0), (131072, 320, 320, 1), (131072, 2560, 320, 2), (32768, 5120, 640, 2)]:
+    geglu = res == 2                                            # (res = 2: the GEGLU form, tile config 6)
     a, w, b = rnd(m, k), rnd(n, k, scale=1 / math.sqrt(k)), torch.randn(n, device="cuda")
-    r = rnd(m, n) if res else None
-    out = torch.empty(m, n, device="cuda", dtype=torch.bfloat16)
+    r = rnd(m, n) if res == 1 else None
+    out = torch.empty(m, n // 2 if geglu else n, device="cuda", dtype=torch.bfloat16)
     ws = torch.zeros(64 * 2 * 512, device="cuda", dtype=torch.int64)
     for _ in range(3):
-        L.call("mvd_op_linear", p(a), None, k, 0, p(w), p(b), None, 0, 0, p(r), 1.0, 0, p(out), 0, m, n, 7, 1, C.c_void_p(ws.data_ptr()), st)
+        L.call("mvd_op_linear", p(a), None, k, 0, p(w), p(b), None, 0, 0, p(r), 1.0, int(geglu), p(out), 0, m, n, 6 if geglu else 7, 1, C.c_void_p(ws.data_ptr()), st)
     torch.cuda.synchronize()
     s = ws.view(64, 2, 512).cpu()
     nslab = k // 64
