@@ -57,6 +57,8 @@ MVD_DEVINL int fresh_lane() {
 // buffer_store_dwordx4 replaced bf16 pairs of lanes 12..15 / 28..31 / ... by halves of the fp32 product (NaNs in the
 // output).  The asm READS the data registers, so whatever overwrites them is ordered behind the two wait states.
 MVD_DEVINL void store16(u32x4 v, __amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+  // (default cache policy: with the non-temporal hint, aux = 2, the L2 stops merging the four waves' 160-byte row pieces into
+  //  whole lines -- dense class 10.1 -> 12.2 ms/step, fused-LayerNorm 3.4 -> 5.5, 460 -> 425 fwd/s on the same box)
   __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, soff, 0);
   asm volatile("s_nop 1" :: "v"(v));
 }
