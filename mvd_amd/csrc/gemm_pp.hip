@@ -112,8 +112,11 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
   const int tq = ntiles >> 3, tr = ntiles & 7;
   const int tstart = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
   const int tend = tstart + tq + (xcd < tr ? 1 : 0);
-  int tile = tstart + xj;
-  if (tile >= tend) return;
+  // (A contiguous sub-range per workgroup -- the N tiles of a row block one after the other instead of side by side -- was
+  //  measured for every form: dense +3 %, fused-LayerNorm +6 %, GEGLU +7 % slower; convolutions and split-K within +-1 %.)
+  const int tile_first = tstart + xj, tile_end = tend, tile_step = gx;
+  int tile = tile_first;
+  if (tile >= tile_end) return;
 
   const MvdASeg& cs = a.seg[0];                       // conv segment (AMODE 1, 2)
   const MvdASeg& ds = a.seg[AMODE == 2 ? 1 : 0];      // dense segment (AMODE 0, 2)
@@ -554,8 +557,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
     const int tl = S == 1 ? tile : tile / S;
     const int ks = S == 1 ? 0 : tile - tl * S;
     const int m0 = (tl / ntn) * BM, n0 = (tl % ntn) * BN;
-    const int next_tile = tile + gx;
-    const bool have_next = next_tile < tend;
+    const int next_tile = tile + tile_step;
+    const bool have_next = next_tile < tile_end;
     int nkt0 = 0, nkt1 = 0;
     if (have_next) slab_range(next_tile, nkt0, nkt1);
     for (int kt = kt0; kt < kt1; ++kt) {
@@ -572,7 +575,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
         pend = false;
       }
       // ---- R0
-      if (LNF && kt == kt0 && tile != tstart + xj) issue_consts(n0);   // (the first tile's were issued by the prologue)
+      if (LNF && kt == kt0 && tile != tile_first) issue_consts(n0);   // (the first tile's were issued by the prologue)
       read_frags(cur, 0);
       if (more) {
         if (last_k) setup_loader(next_tile);           // the loader runs ahead into the next work item
