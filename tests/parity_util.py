@@ -51,20 +51,21 @@ def build_pair(cfg_name: str = "tiny", seed: int = 0, cam_dim: int = 1024, cam_h
 
 
 def run_tiny_parity(batch: int = 2, verbose: bool = False, cfg_name: str = "tiny", hw: int = 16, text_len: int = 7,
-                    timestep: int = 500):
+                    timestep: int = 500, cam: bool = True, img: bool = True):
     cam_dim, cam_hidden = (96, 48) if cfg_name == "tiny" else (1024, 512)
     ocfg, params, model = build_pair(cfg_name, 0, cam_dim, cam_hidden)
     inp = make_inputs(ocfg, batch, hw, text_len, 0, cam_dim)
     t0 = time.time()
     feats = {}
-    want = OM.multiview_unet_forward(params, ocfg, inp["sample"], torch.tensor(timestep), inp["text"], inp["src"],
-                                     inp["tgt"], inp["lat"], fourier_proj=inp["proj"], img_ref_scale=0.3,
-                                     cam_modulation_strength=0.2, features_out=feats)
+    want = OM.multiview_unet_forward(params, ocfg, inp["sample"], torch.tensor(timestep), inp["text"], inp["src"] if cam else None,
+                                     inp["tgt"] if cam else None, inp["lat"] if img else None, fourier_proj=inp["proj"],
+                                     img_ref_scale=0.3, cam_modulation_strength=0.2, features_out=feats)
     t_cpu = time.time() - t0
     model.fourier_projection = inp["proj"]
     with torch.no_grad():
-        got = model(inp["sample"].cuda(), torch.tensor(timestep), inp["text"].cuda(), source_camera=inp["src"].cuda(),
-                    target_camera=inp["tgt"].cuda(), source_image_latents=inp["lat"].cuda()).sample
+        got = model(inp["sample"].cuda(), torch.tensor(timestep), inp["text"].cuda(),
+                    source_camera=inp["src"].cuda() if cam else None, target_camera=inp["tgt"].cuda() if cam else None,
+                    source_image_latents=inp["lat"].cuda() if img else None).sample
     torch.cuda.synchronize()
     stats = dict(rel_l2=rel_l2(got, want), max_rel=max_rel(got, want), cpu_seconds=t_cpu,
                  finite=bool(torch.isfinite(got).all()))

@@ -158,6 +158,18 @@ def test_sd21_full_size_parity():
     assert stats["max_rel"] <= TOL_MAX, stats
 
 
+def test_sd21_full_size_parity_base_unet_only():
+    """BASELINE configs[1]: the plain SD-2.1 UNet (no camera, no image conditioning) at full size, B=1 -- the batch-1 kernel
+    choices (64x64 / 128x64 tiles, deep split-K, the two-kernel GroupNorm at 64x64) under the checker."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from tests.parity_util import run_tiny_parity
+    stats = run_tiny_parity(batch=1, verbose=True, cfg_name="sd21", hw=64, text_len=77, cam=False, img=False)
+    assert stats["finite"]
+    assert stats["rel_l2"] <= TOL_L2, stats
+    assert stats["max_rel"] <= TOL_MAX, stats
+
+
 def test_ddpm_step_and_cfg_kernels():
     """Row N2: fused DDPM step / CFG combine kernels vs the oracle algebra."""
     if not torch.cuda.is_available():
