@@ -155,6 +155,7 @@ def main():
     ap.add_argument("--workload", choices=list(WORKLOADS), default="cfg4")
     ap.add_argument("--pairs", type=int, default=0, help="override pairs per GPU")
     ap.add_argument("--cached", action="store_true", help="reuse the step-invariant reference K/V (Q5) instead of re-running the encoder")
+    ap.add_argument("--graph", action="store_true", help="replay each forward as one hipGraphLaunch (mvd_engine_set_graph); pays at batch 1 only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the determinism / cross-path output screens")
@@ -185,6 +186,7 @@ def main():
     model = MultiViewUNet(None, unet_config=UNetConfig.sd21(), init="empty", img_ref_scale=0.3,
                           cam_modulation_strength=0.2, cache_reference=args.cached).to(dev)
     model.eval()
+    model.use_hip_graph = args.graph
     if rank == 0:
         fill_synthetic_weights(model, 0)
     else:
@@ -293,7 +295,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "pairs_per_gpu": pairs, "global_pairs": total_pairs,
-                       "latent": "64x64x4", "text_tokens": 77, "forward": forward_kind,
+                       "latent": "64x64x4", "text_tokens": 77, "forward": forward_kind, "hip_graph": bool(args.graph),
                        "gflop_per_pair": round(flops_pair / 1e9, 2), "parallelism": f"dp{world} (pairs sharded by object)",
                        "weights": "synthetic seeded, SD2.1 shapes (865.9M UNet x2 + 99.2M adapter + 19.1M camera)"},
             "roofline": roofline, "cpu_baseline": cpu, "output_check": check, "kernel_src_sha": kernel_source_sha(),

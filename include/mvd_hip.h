@@ -99,6 +99,14 @@ typedef struct {
 
 int mvd_unet_forward(mvd_engine_t* e, const mvd_forward_args_t* args, void* stream);
 
+/* hipGraph replay of whole forwards.  When enabled, a mvd_unet_forward whose argument block (every pointer, shape and flag),
+ * bound buffers and starting reference-cache state were seen before is replayed as ONE hipGraphLaunch: the first call with
+ * such a key runs normally, the second is stream-captured and instantiated, later ones replay (up to 8 graphs are kept;
+ * registering weights, re-binding buffers or disabling the switch drops them).  The caller must therefore pass the SAME
+ * device buffers every step and refresh their contents in place, on a non-default stream (a capture on the legacy stream is
+ * illegal).  Ignored while profiling is on.  Mirrors SURVEY.md section 7 step 7; there is nothing like it in the reference. */
+int mvd_engine_set_graph(mvd_engine_t* e, int enable);
+
 /* N4 (training.py:60-65, config/train_config.yaml:43): when the image encoder's UNet weights are identical to the
  * base UNet's (frozen base), the encoder pass can read weight set 0 and set 1 need not be registered at all. */
 int mvd_engine_share_encoder_weights(mvd_engine_t* e, int enable);

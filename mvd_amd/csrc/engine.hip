@@ -62,7 +62,26 @@ struct mvd_engine {
   int rc_batch = 0, rc_h = 0, rc_w = 0; bool rc_valid = false; bool rc_keep = false;
   float* cam_emb = nullptr; int cam_batch = 0;
   bool share_encoder = false;       // N4: the encoder pass reads weight set 0 (base UNet == image-encoder UNet)
-  ~mvd_engine() { for (hipEvent_t ev : ev_pool) (void)hipEventDestroy(ev); }
+  // hipGraph replay of whole forwards (mvd_engine_set_graph): one instantiated graph per distinct (arguments, cache state)
+  struct HostState {                  // what a forward leaves behind on the host side
+    std::vector<bf16_t*> refkv, feat_keep;
+    int rc_batch, rc_h, rc_w; bool rc_valid, rc_keep;
+    float* cam_emb; int cam_batch;
+  };
+  HostState host_state() const { return {refkv, feat_keep, rc_batch, rc_h, rc_w, rc_valid, rc_keep, cam_emb, cam_batch}; }
+  void set_host_state(const HostState& h) {
+    refkv = h.refkv; feat_keep = h.feat_keep; rc_batch = h.rc_batch; rc_h = h.rc_h; rc_w = h.rc_w; rc_valid = h.rc_valid;
+    rc_keep = h.rc_keep; cam_emb = h.cam_emb; cam_batch = h.cam_batch;
+  }
+  struct GraphEntry { std::string key; hipGraph_t g; hipGraphExec_t x; HostState after; };
+  bool graph_on = false;
+  std::vector<GraphEntry> graphs;
+  std::vector<std::string> graph_seen;      // keys that ran once un-captured (first-use initialisation happens there)
+  void drop_graphs() {
+    for (auto& ge : graphs) { (void)hipGraphExecDestroy(ge.x); (void)hipGraphDestroy(ge.g); }
+    graphs.clear(); graph_seen.clear();
+  }
+  ~mvd_engine() { drop_graphs(); for (hipEvent_t ev : ev_pool) (void)hipEventDestroy(ev); }
   std::vector<int> temb_off;        // per resnet offset into the fused time_emb_proj output
   int temb_total = 0;
   std::vector<int> tkv_off;         // per transformer column offset into the fused text K/V projection
@@ -745,12 +764,14 @@ int mvd_engine_create(const mvd_config_t* cfg, mvd_engine_t** out) {
 int mvd_engine_destroy(mvd_engine_t* e) { delete e; return 0; }
 
 int mvd_engine_set_weight(mvd_engine_t* e, int set, const char* slot, const void* ptr, int64_t numel, int dtype) {
+  if (e) e->drop_graphs();
   if (!e || set < 0 || set > 1 || !slot || !ptr || numel <= 0 || dtype < 0 || dtype > 1) { mvd_set_error("set_weight: bad argument"); return -1; }
   if ((uintptr_t)ptr & 15) { mvd_set_error("set_weight: '%s' must be 16-byte aligned", slot); return -1; }
   e->w[set][slot] = Weight{ptr, numel, dtype};
   return 0;
 }
 int mvd_engine_clear_weights(mvd_engine_t* e, int set) {
+  if (e) e->drop_graphs();
   if (!e || set < 0 || set > 1) { mvd_set_error("clear_weights: bad argument"); return -1; }
   e->w[set].clear();
   return 0;
@@ -787,6 +808,7 @@ int64_t mvd_engine_refcache_bytes(mvd_engine_t* e, int ref_batch, int height, in
 }
 
 int mvd_engine_bind_workspace(mvd_engine_t* e, void* ws, int64_t ws_bytes, void* refcache, int64_t refcache_bytes) {
+  if (e) e->drop_graphs();
   if (!e || !ws || ws_bytes <= 0) { mvd_set_error("bind_workspace: bad argument"); return -1; }
   if (((uintptr_t)ws & 255) || (refcache && ((uintptr_t)refcache & 255))) { mvd_set_error("bind_workspace: buffers must be 256-byte aligned"); return -1; }
   e->ws_ptr = ws; e->ws_bytes = ws_bytes;
@@ -812,7 +834,49 @@ int mvd_unet_forward(mvd_engine_t* e, const mvd_forward_args_t* args, void* stre
   }
   e->act.base = (char*)e->ws_ptr; e->act.cap = act_bytes;
   e->tmp.base = (char*)e->ws_ptr + act_bytes; e->tmp.cap = (size_t)e->ws_bytes - act_bytes;
-  return forward_impl(e, *args, (hipStream_t)stream, false);
+  hipStream_t st = (hipStream_t)stream;
+  if (!e->graph_on || e->prof || !st) return forward_impl(e, *args, st, false);
+  // ---- hipGraph replay.  A forward is a pure function of the argument block (pointers, shapes, flags), the bound buffers
+  // and the reference-cache state it starts from; the host-side state it leaves behind is the same every time.  The first
+  // call with a given key runs as usual (kernels' first-use set-up must not happen inside a capture), the second is
+  // captured and instantiated, later ones are one hipGraphLaunch.
+  std::string key((const char*)args, sizeof(*args));
+  const int st8[8] = {e->rc_valid, e->rc_batch, e->rc_h, e->rc_w, e->rc_keep, e->share_encoder, 0, 0};
+  key.append((const char*)st8, sizeof(st8));
+  key.append((const char*)&e->ws_ptr, sizeof(void*));
+  key.append((const char*)&e->rc_ptr, sizeof(void*));
+  for (auto& ge : e->graphs)
+    if (ge.key == key) {
+      hipError_t he = hipGraphLaunch(ge.x, st);
+      if (he != hipSuccess) { mvd_set_error("forward: hipGraphLaunch: %s", hipGetErrorString(he)); return -7; }
+      e->set_host_state(ge.after);        // (same key => the captured run started from this state and ended in that one)
+      return 0;
+    }
+  bool seen = false;
+  for (auto& k : e->graph_seen) seen |= k == key;
+  if (!seen) { e->graph_seen.push_back(key); return forward_impl(e, *args, st, false); }
+  if (e->graphs.size() >= 8) e->drop_graphs();
+  hipError_t he = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+  if (he != hipSuccess) { mvd_set_error("forward: hipStreamBeginCapture: %s", hipGetErrorString(he)); return -7; }
+  r = forward_impl(e, *args, st, false);
+  hipGraph_t g = nullptr;
+  he = hipStreamEndCapture(st, &g);
+  if (r) { if (g) (void)hipGraphDestroy(g); return r; }
+  if (he != hipSuccess || !g) { mvd_set_error("forward: hipStreamEndCapture: %s", hipGetErrorString(he)); return -7; }
+  hipGraphExec_t x = nullptr;
+  he = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
+  if (he != hipSuccess) { (void)hipGraphDestroy(g); mvd_set_error("forward: hipGraphInstantiate: %s", hipGetErrorString(he)); return -7; }
+  e->graphs.push_back({key, g, x, e->host_state()});
+  he = hipGraphLaunch(x, st);
+  if (he != hipSuccess) { mvd_set_error("forward: hipGraphLaunch: %s", hipGetErrorString(he)); return -7; }
+  return 0;
+}
+
+int mvd_engine_set_graph(mvd_engine_t* e, int enable) {
+  if (!e) { mvd_set_error("set_graph: null engine"); return -1; }
+  e->graph_on = enable != 0;
+  if (!e->graph_on) e->drop_graphs();
+  return 0;
 }
 
 int mvd_engine_set_profiling(mvd_engine_t* e, int enable) {
@@ -862,6 +926,7 @@ int mvd_engine_profile_shapes(mvd_engine_t* e, char* buf, int cap) {
 }
 
 int mvd_engine_share_encoder_weights(mvd_engine_t* e, int enable) {
+  if (e) e->drop_graphs();
   if (!e) { mvd_set_error("share_encoder_weights: null engine"); return -1; }
   e->share_encoder = enable != 0;
   return 0;

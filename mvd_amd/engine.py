@@ -157,7 +157,19 @@ class MVDEngine:
             ref_batch = source_latents.shape[0] if source_latents is not None else self._last_ref_batch
             self._last_ref_batch = ref_batch
         self._ensure_workspace(B, H, W, Lt, ref_batch, keep_features)
-        if out is None:
+        graph = getattr(self, "_graph", False)
+        user_out = out
+        if graph:
+            # hipGraph replay needs the SAME device buffers every call: stage the inputs into persistent buffers (tiny
+            # device-to-device copies on the caller's stream) and run on the engine's own stream (captures are illegal on the
+            # legacy default stream); mvd_engine_set_graph in include/mvd_hip.h
+            stage = lambda name, t: None if t is None else self._staged(name, t)   # noqa: E731
+            sample, timesteps, text = stage("sample", sample), stage("timesteps", timesteps), stage("text", text)
+            source_camera, target_camera = stage("src_cam", source_camera), stage("tgt_cam", target_camera)
+            fourier_proj, source_latents = stage("proj", fourier_proj), stage("lat", source_latents)
+            encoder_text = stage("enc_text", encoder_text)
+            out = self._staged("out", torch.empty(0), shape=(B, self.cfg.out_channels, H, W))
+        elif out is None:
             out = torch.empty(B, self.cfg.out_channels, H, W, dtype=torch.float32, device=self.device)
         a = L.mvd_forward_args_t()
         a.batch, a.height, a.width, a.text_len = B, H, W, Lt
@@ -187,10 +199,35 @@ class MVDEngine:
                 flags |= L.MVD_KEEP_FEATURES
         a.ref_batch, a.flags = ref_batch, flags
         a.out = out.data_ptr()
-        L.call("mvd_unet_forward", self._h, C.byref(a), _stream())
+        if graph:
+            cur = torch.cuda.current_stream(self.device)
+            self._gstream.wait_stream(cur)
+            with torch.cuda.stream(self._gstream):
+                L.call("mvd_unet_forward", self._h, C.byref(a), _stream())
+            cur.wait_stream(self._gstream)
+            out = out.clone() if user_out is None else user_out.copy_(out)
+        else:
+            L.call("mvd_unet_forward", self._h, C.byref(a), _stream())
         if use_img and not reuse_ref:
             self._ref_valid = (B, H, W, Lt, ref_batch)
         return out
+
+    def set_graph(self, enable: bool) -> None:
+        """Replay repeated forwards (same shapes / flags) as one hipGraphLaunch each (``mvd_engine_set_graph``)."""
+        L.call("mvd_engine_set_graph", self._h, int(bool(enable)))
+        self._graph = bool(enable)
+        if enable and getattr(self, "_gstream", None) is None:
+            self._gstream = torch.cuda.Stream(device=self.device)
+            self._gbufs = {}
+
+    def _staged(self, name: str, t: torch.Tensor, shape=None) -> torch.Tensor:
+        shape = tuple(t.shape) if shape is None else tuple(shape)
+        buf = self._gbufs.get((name, shape))
+        if buf is None:
+            buf = self._gbufs[(name, shape)] = torch.empty(shape, dtype=torch.float32, device=self.device)
+        if name != "out":
+            buf.copy_(t)
+        return buf
 
     def reference_cache_valid(self, batch, h, w, text_len, ref_batch) -> bool:
         """True when the engine still holds reference K/V computed for exactly this shape (Q5 reuse is then legal)."""
