@@ -1039,6 +1039,7 @@ int mvd_op_conv3x3(const void* x, int batch, int in_h, int in_w, int cin, int st
   g.W = (const bf16_t*)w; g.ldw = g.Ktot; g.M = batch * oh * ow; g.N = cout; g.rows_per_batch = oh * ow; g.outH = oh; g.outW = ow;
   g.bias = bias; g.rowvec = rowvec; g.ld_rowvec = ld_rowvec; g.res = (const bf16_t*)res; g.ldres = cout; g.alpha = 1.f;
   g.out = out; g.ldo = cout;
+  g.part = splitk_ws;      // (also the stamp buffer of probe builds)
   if (splitk > 1) {
     g.splitk = splitk; g.part = splitk_ws;
     if (int r = mvd_launch_gemm(g, (hipStream_t)stream, force_cfg)) return r;

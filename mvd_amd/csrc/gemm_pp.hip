@@ -17,19 +17,19 @@
 //   but the second group executes one extra s_barrier up front.  A slab is four phases, each closed by a barrier:
 //       R0: ds_read the fragments of k 0..31 into registers, issue LDS-DMAs of the NEXT slab
 //       M0: 40 MFMAs out of registers (s_setprio 1)
-//       R1: ds_read the fragments of k 32..63 (group 0: the rest of the next slab's W loads; group 1: wait for its loads)
-//       M1: 40 MFMAs (group 0: then wait for its loads)
+//       R1: ds_read the fragments of k 32..63, issue the rest of the next slab's loads
+//       M1: 40 MFMAs, then wait for the group's loads
 //   so at any time one wave of a SIMD is in an MFMA-only phase while its partner reads LDS / issues loads: the matrix
 //   pipe always has a wave to serve.  DMAs stay in flight across barriers (raw s_barrier, explicit waits); the epilogues
 //   of the two groups run in one common phase E per tile.
 //
 // Hazard bookkeeping (g = barrier generation; group 0 passes its p-th program barrier at g = p, group 1 at p + 1;
 // slab t occupies program barriers 4t .. 4t+3):
-//   WAR  stage (t+1)&1 is re-filled by DMAs issued in R0(t): group 0 in (4t-1, 4t], group 1 in (4t, 4t+1].  Its last
-//        readers are the R1(t-1) phases, closed (with lgkmcnt(0)) by barriers 4t-2 / 4t-1.
-//        (group 0 also issues in its R1(t), (4t+1, 4t+2]: later still.)
-//   RAW  slab t+1 is first read by group 0 in R0(t+1), after barrier 4t+3.  Group 0 waits for its DMAs before barrier
-//        4t+3 (end of its M1(t)), group 1 before barrier 4t+3 (end of its R1(t)).
+// A group loads the A rows only it reads; W (read by both) is loaded by group 0.
+//   WAR  stage (t+1)&1 is re-filled by DMAs issued in R0(t) / R1(t): group 0 from (4t-1, 4t] on, group 1 from (4t, 4t+1].
+//        Its last readers are the R1(t-1) phases, closed (with lgkmcnt(0)) by barriers 4t-2 / 4t-1.
+//   RAW  W of slab t+1 is first read by group 0 in R0(t+1), after barrier 4t+3; group 0 waits for its DMAs before that
+//        barrier (end of its M1(t)).  Group 1's A rows are first read in ITS R0(t+1); it waits at the end of its M1(t).
 #include <stdlib.h>
 #include <string.h>
 #include "kernels.h"
@@ -88,7 +88,8 @@ template <int BM, int WM, int WN, int AMODE, bool SPLITK, bool LNF = false>
 __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
   static_assert(!LNF || (AMODE == 0 && !SPLITK), "the LayerNorm fold is a dense, unsplit form");
   constexpr int A_BYTES = BM * 128, STAGE_BYTES = A_BYTES + B_BYTES;
-  constexpr int A_IT = BM * 8 / NT;                       // A-side DMA instructions per wave per slab (4 / 2)
+  constexpr int A_IT = BM * 8 / NT;                       // A-side DMA instructions per wave per slab
+  static_assert(A_IT == 4, "the A loader below is written for 256-row tiles");
   constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 16, TN = WTN / 16;
   constexpr bool GEGLU = WM == 4;
   constexpr bool HAS_CONV = AMODE != 0;
@@ -101,8 +102,15 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
   const int wm = wave / WN, wn = wave % WN;
   const int ntn = a.N / BN;
   const int ntm = (a.M + BM - 1) / BM;
-  const int lrow = tid >> 3;                                      // 0..63: row inside a 64-row DMA block
+  const int lrow = tid >> 3;                                      // 0..63: row inside a 64-row DMA block (W loads)
   const int kc = (tid & 7) ^ ((lrow >> 1) & 7);                   // source chunk (the XOR swizzle lives on the source side)
+  // A loads: EACH GROUP LOADS THE ROWS IT MULTIPLIES (group g = row block wm's half: rows 128 g .. 128 g + 127 of the tile, the
+  // 64-row blocks 2g and 2g + 1).  Load i of wave w (w4 = w & 3) is the 8-row slice w4 + 4 (i >> 1) of block 2g + (i & 1);
+  // slices w4 and w4 + 4 have the same swizzle parity, so kc above serves both.  Nobody but group g reads those rows, so
+  // group 1 may issue half of its A loads as late as its R1 and wait for them at the end of its M1 (one phase of cover,
+  // like group 0) -- its R0, the long pole against group 0's 640-cycle MFMA phase, carries two loads instead of four.
+  const int w4 = wave & 3;
+  const int arow = w4 * 8 + (lane >> 3);                          // row inside the block of the i < 2 loads; i >= 2: + 32
 
   // ---- tile walk (as gemm.hip): XCD x owns a contiguous range of work items, its workgroups stride through it
   const int S = SPLITK ? a.splitk : 1;
@@ -145,8 +153,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
   // loop-invariant per-lane offsets: row-in-block * pitch + chunk.  Rows >= M of a dense source lie beyond num_records
   // and read as zeros (their outputs are never stored).
   const unsigned voff_w = (unsigned)lrow * (unsigned)a.ldw * 2u + kc * 16;
-  const unsigned voff_d0 = (unsigned)lrow * (unsigned)dc0 * 2u + kc * 16;
-  const unsigned voff_d1 = (unsigned)lrow * (unsigned)dc1 * 2u + kc * 16;
+  const unsigned voff_d0 = (unsigned)arow * (unsigned)dc0 * 2u + kc * 16;
+  const unsigned voff_d1 = (unsigned)arow * (unsigned)dc1 * 2u + kc * 16;
 
   // ---- loader state of the tile whose slabs are being fetched (may run one tile ahead of the multiplying tile)
   int ld_m0 = 0, ld_n0 = 0;
@@ -159,7 +167,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
     if (HAS_CONV) {
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) {
-        int m = ld_m0 + lrow + i * 64;
+        int m = ld_m0 + (2 * grp + (i & 1)) * 64 + arow + (i >> 1) * 32;
         m = m < a.M ? m : a.M - 1;
         const int b = m / a.rows_per_batch;
         const int rem = m - b * a.rows_per_batch;
@@ -174,14 +182,13 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
     }
   };
 
-  // LDS-DMAs of slab lk (of the loader's tile) into stage st.  The A operand is loaded by all eight waves (each its own
-  // 8-row slice of every 64-row block: the convolution's per-lane window state belongs to that slice); the W operand -- whose
-  // offsets are scalar apart from one invariant per-lane term -- is loaded by GROUP 0 ALONE (both slices w and w+4 of each
-  // block), spread over its two read phases.  Per slab group 0 issues 4 + 3 loads in R0 and 7 in R1, group 1 its 4 A loads in
-  // R0: no phase carries more than 7 of the 72 loads of a slab (evenly split, R0 carried 9 per wave and was the long pole
-  // against the partner's 640-cycle MFMA phase).
-  auto issue_a = [&](int st, int lk) {
-    unsigned char* sa = smem + st * STAGE_BYTES + wave * 1024;
+  // LDS-DMAs of slab lk (of the loader's tile) into stage st.  Each group loads the 128 A rows it multiplies (four loads per
+  // wave, see above); the W operand -- whose offsets are scalar apart from one invariant per-lane term -- is loaded by GROUP 0
+  // ALONE (both slices w and w+4 of each block), spread over its two read phases.  Per slab group 0 issues 4 + 3 loads in R0
+  // and 7 in R1, group 1 two A loads in R0 and two in R1: the read phases are what the partner's 640-cycle MFMA phase waits for.
+  auto issue_a = [&](int st, int lk, int i0, int i1) {
+    // LDS image of the A operand: [64-row block][8-row slice][8 rows][128 B]; load i -> block 2g + (i & 1), slice w4 + 4 (i >> 1)
+    unsigned char* sa = smem + st * STAGE_BYTES + (2 * grp) * 8192 + w4 * 1024;
     if (HAS_CONV && (AMODE != 2 || lk < nkt_conv)) {
       // K order [channel slice][tap][64 channels] (gemm.hip): slice = lk / 9, tap = lk % 9
       const int sl = lk / 9, tap = lk - sl * 9;
@@ -198,7 +205,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
           if (dy == 1) vo += (a_yx[i] & 1) ? 0u : (unsigned)conv_rowB;
           if (dx == 1) vo += (a_yx[i] & 0x10000) ? 0u : (unsigned)conv_c2;
         }
-        dma16(rs_c, sa + i * 8192, ok ? vo : OOB, soff);
+        if (i >= i0 && i < i1) dma16(rs_c, sa + (i & 1) * 8192 + (i >> 1) * 4096, ok ? vo : OOB, soff);
       }
     } else {
       const int cc = (lk - nkt_conv) << 6;             // first K column of the slab inside the dense segment
@@ -207,14 +214,15 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
       const unsigned col2 = (unsigned)((first ? cc : cc - dc0) * 2);
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) {
-        const unsigned soff = (unsigned)(ld_m0 + i * 64) * (unsigned)pitch + col2;
-        if (first) dma16(rs_d0, sa + i * 8192, voff_d0, soff);
-        else dma16(rs_d1, sa + i * 8192, voff_d1, soff);
+        if (i < i0 || i >= i1) continue;
+        const unsigned soff = (unsigned)(ld_m0 + (2 * grp + (i & 1)) * 64 + (i >> 1) * 32) * (unsigned)pitch + col2;
+        if (first) dma16(rs_d0, sa + (i & 1) * 8192 + (i >> 1) * 4096, voff_d0, soff);
+        else dma16(rs_d1, sa + (i & 1) * 8192 + (i >> 1) * 4096, voff_d1, soff);
       }
     }
   };
   // W loads q0 <= q < q1 of group 0's ten per slab: q -> (64-row block q >> 1, 8-row slice wave + 4 * (q & 1))
-  constexpr int W_Q = 2 * B_IT, W_Q_R0 = 3;
+  constexpr int W_Q = 2 * B_IT, W_Q_R0 = 3;   // (1: R0 shorter in isolation, but 7 -> 9 late loads expose their latency in situ: conv +2 %, split-K +5 % slower)
   auto issue_w = [&](int st, int lk, int q0, int q1) {
     unsigned char* sb = smem + st * STAGE_BYTES + A_BYTES + wave * 1024;
     const unsigned ldw2 = (unsigned)a.ldw * 2u;
@@ -536,7 +544,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
   int kt0, kt1;
   slab_range(tile, kt0, kt1);
   setup_loader(tile);
-  issue_a(0, kt0);
+  issue_a(0, kt0, 0, A_IT);
   if (grp == 0) issue_w(0, kt0, 0, W_Q);
   issue_consts(ld_n0);
   init_acc();
@@ -579,8 +587,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
       read_frags(cur, 0);
       if (more) {
         if (last_k) setup_loader(next_tile);           // the loader runs ahead into the next work item
-        issue_a(cur ^ 1, nlk);
-        if (grp == 0) issue_w(cur ^ 1, nlk, 0, W_Q_R0);
+        if (grp == 0) { issue_a(cur ^ 1, nlk, 0, A_IT); issue_w(cur ^ 1, nlk, 0, W_Q_R0); }
+        else issue_a(cur ^ 1, nlk, 0, A_IT / 2);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       phase_end();
@@ -593,12 +601,13 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
         if (more) issue_w(cur ^ 1, nlk, W_Q_R0, W_Q);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       } else {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // group 1's loads of the next slab (issued in its R0) have landed
+        if (more) issue_a(cur ^ 1, nlk, A_IT / 2, A_IT);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
       phase_end();
       // ---- M1
       mfma_half();
-      if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // group 0's loads (R0 + R1) have landed: one MFMA phase of cover
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the group's loads (R0 + R1) have landed: one MFMA phase of cover
       phase_end();
       if (last_k) { pend = true; pm0 = m0; pn0 = n0; pks = ks; }
       cur ^= 1;
