@@ -159,7 +159,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
   // ---- loader state of the tile whose slabs are being fetched (may run one tile ahead of the multiplying tile)
   int ld_m0 = 0, ld_n0 = 0;
   unsigned a_base[A_IT];      // conv: byte offset of the window's top-left tap (shifted origin), + chunk
-  int a_yx[A_IT];             // conv: (oy*stride) | (ox*stride) << 16
+  int a_yx[A_IT];             // conv: (oy*stride) | (ox*stride) << 16 | in-image mask of the 9 taps << 22 (bit 22 + tap)
   auto setup_loader = [&](int work) {
     const int t = S == 1 ? work : work / S;
     ld_m0 = (t / ntn) * BM;
@@ -173,7 +173,15 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
         const int rem = m - b * a.rows_per_batch;
         const int oy = rem / a.outW, ox = rem - oy * a.outW;
         const int ys = oy * cs.stride + cs.asym, xs = ox * cs.stride + cs.asym;   // asym: the window starts AT (2oy, 2ox)
-        a_yx[i] = ys | (xs << 16);
+        // which of the nine taps fall inside the image: worked out once per tile (the slab loop then tests one bit per
+        // load instead of re-deriving both coordinates and comparing them -- the read phases are the long pole)
+        int okm = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int iy = ys - 1 + t / 3, ix = xs - 1 + t % 3;
+          okm |= ((unsigned)iy < (unsigned)limH && (unsigned)ix < (unsigned)limW) ? (1 << t) : 0;
+        }
+        a_yx[i] = (ys & 0x7ff) | ((xs & 0x7ff) << 11) | (okm << 22);
         // top-left tap (ys-1, xs-1) in source coordinates; with the fused nearest-2x upsample the source row of
         // upsampled row r is r >> 1 (arithmetic), the parity-dependent +1 of the middle tap is added per load
         const int ty = conv_ups ? ((ys - 1) >> 1) : ys - 1, tx = conv_ups ? ((xs - 1) >> 1) : xs - 1;
@@ -198,12 +206,11 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
       else soff += (unsigned)((dy == 2 ? conv_rowB : 0) + (dx == 2 ? conv_c2 : 0));
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) {
-        const int iy = (a_yx[i] & 0xffff) - 1 + dy, ix = (a_yx[i] >> 16) - 1 + dx;
-        const bool ok = (unsigned)iy < (unsigned)limH && (unsigned)ix < (unsigned)limW;
+        const bool ok = (a_yx[i] >> (22 + tap)) & 1;
         unsigned vo = a_base[i];
         if (conv_ups) {   // middle tap: +1 source row/pixel iff the upsampled coordinate (ys-1 / xs-1) is odd, i.e. ys / xs even
           if (dy == 1) vo += (a_yx[i] & 1) ? 0u : (unsigned)conv_rowB;
-          if (dx == 1) vo += (a_yx[i] & 0x10000) ? 0u : (unsigned)conv_c2;
+          if (dx == 1) vo += (a_yx[i] & 0x800) ? 0u : (unsigned)conv_c2;
         }
         if (i >= i0 && i < i1) dma16(rs_c, sa + (i & 1) * 8192 + (i >> 1) * 4096, ok ? vo : OOB, soff);
       }
@@ -672,7 +679,7 @@ bool mvd_gemm_pp_applicable(const MvdGemmArgs& a) {
     } else {
       const size_t bytes = (size_t)(a.M / a.rows_per_batch) * g.inH * g.inW * g.c0 * 2 + (size_t)(g.inW + 1) * g.c0 * 2;
       if (bytes + (size_t)3 * g.inW * g.c0 * 2 >= lim) return false;
-      if (2 * g.inH >= 32768 || 2 * g.inW >= 32768) return false;     // (y, x) packed in 16 bits each
+      if (2 * g.inH >= 32768 || 2 * g.inW >= 32768) return false;     // (int arithmetic on pixel coordinates)
     }
   }
   return true;
