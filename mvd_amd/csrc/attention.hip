@@ -72,7 +72,9 @@ MVD_DEVINL void attn_block(const MvdAttnArgs& a, int& qb, int& head, int& bz) {
   bz = pair / a.heads;
 }
 
-template <int NW, int NSUB, bool PRE>
+// DMA: K/V tiles go global -> LDS by buffer-addressed LDS-DMA (no VGPR round trip, no ds_write, 16 registers fewer; the XOR
+// swizzles move to the source side; keys >= nk lie beyond num_records and arrive as zeros) instead of load + ds_write.
+template <int NW, int NSUB, bool PRE, bool DMA = false>
 __global__ __launch_bounds__(64 * NW, (NW == 4 && NSUB == 2) ? 3 : 2) void attn_kernel(const MvdAttnArgs a) {
   constexpr int NT = 64 * NW;
   constexpr int QB = 32 * NW;
@@ -80,7 +82,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && NSUB == 2) ? 3 : 2) void attn_
   constexpr int TILE_BYTES = KV_TILE * 128;         // keys x 64 dims x 2 B
   constexpr int LD_IT = (KV_TILE * 8) / NT;         // 16-byte chunks per thread per tile
   static_assert((KV_TILE * 8) % NT == 0, "tile must divide over threads");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];  // K0 K1 V0 V1
+  static_assert(!DMA || (NT / 8) % 16 == 0, "DMA rows of a lane share the swizzle pattern");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];         // 4 * TILE_BYTES: K0 K1 V0 V1
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 31, lh = lane >> 5;
@@ -119,8 +122,24 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && NSUB == 2) ? 3 : 2) void attn_
   const unsigned ld_vo = ((unsigned)ld_row * (unsigned)ldv + ld_kc * 8) * 2u;
   const char* kp_b = reinterpret_cast<const char*>(kp);
   const char* vp_b = reinterpret_cast<const char*>(vp);
-  u32x4 rk[LD_IT], rv[LD_IT];
+  typedef __attribute__((address_space(3))) void lds_void_t;
+  __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(kp), 0, (nk - 1) * ldk * 2 + 128, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vp), 0, (nk - 1) * ldv * 2 + 128, 0x00020000);
+  const unsigned dma_ko = (unsigned)ld_row * (unsigned)ldk * 2u + ((ld_kc ^ ((ld_row >> 1) & 7)) << 4);
+  const unsigned dma_vo = (unsigned)ld_row * (unsigned)ldv * 2u + ((ld_kc ^ (((ld_row >> 1) & 1) << 2)) << 4);
+  auto dma_tile = [&](int kb, int st) {            // tile kb -> stage st (lane-linear LDS image, swizzled source chunk)
+    unsigned char* dk = smem + st * TILE_BYTES + wave * 1024;
+    unsigned char* dv = smem + (2 + st) * TILE_BYTES + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < LD_IT; ++i) {
+      const int row0 = kb * KV_TILE + i * (NT / 8);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lds_void_t*)(dk + i * (NT / 8) * 128), 16, (int)dma_ko, row0 * ldk * 2, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lds_void_t*)(dv + i * (NT / 8) * 128), 16, (int)dma_vo, row0 * ldv * 2, 0, 0);
+    }
+  };
+  u32x4 rk[DMA ? 1 : LD_IT], rv[DMA ? 1 : LD_IT];
   auto load_tile = [&](int kb) {
+    if constexpr (DMA) return;
     const int k0 = kb * KV_TILE;
     const bool full = k0 + KV_TILE <= nk;          // uniform
 #pragma unroll
@@ -144,6 +163,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && NSUB == 2) ? 3 : 2) void attn_
     }
   };
   auto store_tile = [&](int st) {
+    if constexpr (DMA) return;
     unsigned char* sk = smem + st * TILE_BYTES;
     unsigned char* sv = smem + (2 + st) * TILE_BYTES;
 #pragma unroll
@@ -168,6 +188,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && NSUB == 2) ? 3 : 2) void attn_
   f32x16 negm = {};              // PRE: -m_run in every register (C operand that starts each score tile)
 
   const int nkb = (nk + KV_TILE - 1) / KV_TILE;
+  if constexpr (DMA) { dma_tile(0, 0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
   load_tile(0);
   store_tile(0);
   __syncthreads();
@@ -187,7 +208,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && NSUB == 2) ? 3 : 2) void attn_
   for (int kb = 0; kb < nkb; ++kb) {
     const int cur = kb & 1;
     const bool more = kb + 1 < nkb;
-    if (more) load_tile(kb + 1);
+    if (more) { if constexpr (DMA) dma_tile(kb + 1, cur ^ 1); else load_tile(kb + 1); }   // (stage cur^1: last read before the previous barrier)
     const unsigned char* sk = smem + cur * TILE_BYTES;
     const unsigned char* sv = smem + (2 + cur) * TILE_BYTES;
 
@@ -288,6 +309,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && NSUB == 2) ? 3 : 2) void attn_
       ol = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones_frag, pb, ol, 0, 0, 0);
     }
     if (more) store_tile(cur ^ 1);
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 
@@ -773,8 +795,14 @@ int launch_nw(const MvdAttnArgs& a, int maxq, hipStream_t s) {
   static const int pipe = MVD_ENV_INT("MVD_ATTN_PIPE", 0);
   g_last_attn[0] = NW; g_last_attn[1] = (int)grid.x;
   if (a.prescaled && NW == 4 && NSUB == 2 && pipe) hipLaunchKernelGGL((attn_pipe_kernel<4>), grid, dim3(256), 0, s, a);
-  else if (a.prescaled) hipLaunchKernelGGL((attn_kernel<NW, NSUB, true>), grid, dim3(64 * NW), 0, s, a);
-  else                  hipLaunchKernelGGL((attn_kernel<NW, NSUB, false>), grid, dim3(64 * NW), 0, s, a);
+  else if (a.prescaled) {
+#ifdef MVD_ATTN_NO_DMA          // (A/B builds)
+    constexpr bool dma = false;
+#else
+    constexpr bool dma = NW == 4 && NSUB == 2;
+#endif
+    hipLaunchKernelGGL((attn_kernel<NW, NSUB, true, dma>), grid, dim3(64 * NW), 4 * 32 * NSUB * 128, s, a);
+  } else hipLaunchKernelGGL((attn_kernel<NW, NSUB, false>), grid, dim3(64 * NW), 4 * 32 * NSUB * 128, s, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { mvd_set_error("attention launch: %s", hipGetErrorString(e)); return -3; }
   return 0;
