@@ -74,8 +74,10 @@ MVD_DEVINL void attn_block(const MvdAttnArgs& a, int& qb, int& head, int& bz) {
 
 // DMA: K/V tiles go global -> LDS by buffer-addressed LDS-DMA (no VGPR round trip, no ds_write, 16 registers fewer; the XOR
 // swizzles move to the source side; keys >= nk lie beyond num_records and arrive as zeros) instead of load + ds_write.
-template <int NW, int NSUB, bool PRE, bool DMA = false>
-__global__ __launch_bounds__(64 * NW, (NW == 4 && NSUB == 2) ? 3 : 2) void attn_kernel(const MvdAttnArgs a) {
+// VSUM (with DMA): the softmax denominators are summed with v_dot2c_f32_bf16 on the packed P instead of the "ones" V^T tile --
+// 16 accumulator registers and 2 of 20 MFMAs per tile less, which brings the kernel under 128 registers: FOUR waves per SIMD.
+template <int NW, int NSUB, bool PRE, bool DMA = false, bool VSUM = false>
+__global__ __launch_bounds__(64 * NW, VSUM ? 4 : ((NW == 4 && NSUB == 2) ? 3 : 2)) void attn_kernel(const MvdAttnArgs a) {
   constexpr int NT = 64 * NW;
   constexpr int QB = 32 * NW;
   constexpr int KV_TILE = 32 * NSUB;
@@ -180,6 +182,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && NSUB == 2) ? 3 : 2) void attn_
 
   f32x16 o0 = {}, o1 = {};       // O^T tiles: d 0..31 and 32..63 (rows) x query (lane)
   f32x16 ol = {};                // "ones" tile: row 0 (reg 0 of lanes 0..31) = running softmax denominators
+  float lsum = 0.f;              // VSUM: this lane's share (its half of the keys) of the denominator of query lq
   bf16x8 ones_frag;
 #pragma unroll
   for (int j = 0; j < 8; ++j) ones_frag[j] = (lq == 0) ? (__bf16)1.0f : (__bf16)0.0f;
@@ -254,6 +257,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && NSUB == 2) ? 3 : 2) void attn_
 #pragma unroll
           for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
           ol[0] *= alpha;
+          lsum *= alpha;
         }
         m_run += delta;
 #pragma unroll
@@ -306,7 +310,16 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && NSUB == 2) ? 3 : 2) void attn_
       }
       // row sums on the matrix pipe (the softmax VALU stream is the bottleneck at head_dim 64): a V^T tile whose
       // row 0 is all ones accumulates sum_k P[k][q] -- of the SAME bf16-rounded P the numerator uses -- into ol[0]
-      ol = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones_frag, pb, ol, 0, 0, 0);
+      if constexpr (VSUM) {
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+        const bf16x2_t ones2 = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
+        const u32x4 pw = __builtin_bit_cast(u32x4, pb);
+        const unsigned w4[4] = {pw.x, pw.y, pw.z, pw.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lsum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w4[e]), ones2, lsum, false);
+      } else {
+        ol = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones_frag, pb, ol, 0, 0, 0);
+      }
     }
     if (more) store_tile(cur ^ 1);
     if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -314,7 +327,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && NSUB == 2) ? 3 : 2) void attn_
   }
 
   // ---- epilogue: O[q][d] = O^T / l ; lane holds d = 32*dt + (r&3) + 8*(r>>2) + 4*lh
-  const float inv = 1.0f / pair_sum(ol[0]);   // lanes 32..63 hold row 4 of the ones tile (= 0) in ol[0]
+  const float inv = 1.0f / pair_sum(VSUM ? lsum : ol[0]);   // lanes 32..63 hold row 4 of the ones tile (= 0) in ol[0]
   if (qrow < nq) {
     bf16_t* orow = op + (size_t)qrow * P.ldo;
 #pragma unroll
@@ -801,7 +814,12 @@ int launch_nw(const MvdAttnArgs& a, int maxq, hipStream_t s) {
 #else
     constexpr bool dma = NW == 4 && NSUB == 2;
 #endif
-    hipLaunchKernelGGL((attn_kernel<NW, NSUB, true, dma>), grid, dim3(64 * NW), 4 * 32 * NSUB * 128, s, a);
+#ifdef MVD_ATTN_NO_VSUM         // (A/B builds)
+    constexpr bool vsum = false;
+#else
+    constexpr bool vsum = dma;
+#endif
+    hipLaunchKernelGGL((attn_kernel<NW, NSUB, true, dma, vsum>), grid, dim3(64 * NW), 4 * 32 * NSUB * 128, s, a);
   } else hipLaunchKernelGGL((attn_kernel<NW, NSUB, false>), grid, dim3(64 * NW), 4 * 32 * NSUB * 128, s, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { mvd_set_error("attention launch: %s", hipGetErrorString(e)); return -3; }
