@@ -9,7 +9,7 @@ B = 32
 which = os.environ.get("PMC_OPS", "attn,conv,lin,geglu").split(",")
 if "attn" in which:
     q, k, v = rnd(B, 4096, 320), rnd(B, 4096, 320), rnd(B, 4096, 320)
-    for _ in range(3): ops.attention(q, k, v, 5)
+    for _ in range(3): ops.attention(q, k, v, 5, scale=0.0)      # the engine's form: prescaled q, LDS-DMA staging, dot2c denominators
 if "conv" in which:
     x, w = rnd(B, 32, 32, 640), rnd(640, 9 * 640)
     for _ in range(3): ops.conv3x3(x, w, force_cfg=7)
