@@ -106,16 +106,32 @@ def cpu_baseline(timed_runs: int = 3, warmup_runs: int = 1):
                       f"torch fp32 on {cores} host threads (os.cpu_count()={os.cpu_count()}), {med:.2f} s/forward"}
 
 
-def kernel_source_sha() -> str:
-    """Hash of the HIP sources + headers the library is built from: PMC summaries under profiles/ are stamped with it,
-    and ``roofline.traffic`` is only quoted from a summary taken on THIS source state."""
+def _strip_comments(src: str) -> str:
+    """Drop // and /* */ comments, blank lines and leading / trailing white space (string literals in the kernels never
+    contain comment markers): what remains decides the generated code."""
+    import re
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = []
+    for line in src.splitlines():
+        line = re.sub(r"//.*$", "", line).strip()
+        if line:
+            out.append(line)
+    return "\n".join(out)
+
+
+def kernel_source_sha(read=None) -> str:
+    """Hash of the HIP sources + headers the library is built from, comments and blank lines excluded: PMC summaries under
+    profiles/ are stamped with it, and ``roofline.traffic`` is only quoted from a summary taken on THIS code state.
+    ``read(path) -> str`` lets a tool hash another revision of the same files."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "mvd_amd", "csrc")
     for f in sorted(os.listdir(d)):
         if f.endswith((".hip", ".h")):
+            path = os.path.join(d, f)
+            text = read(path) if read else open(path, "r").read()
             h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+            h.update(_strip_comments(text).encode())
     return h.hexdigest()[:16]
 
 

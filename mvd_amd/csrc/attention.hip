@@ -15,13 +15,17 @@
 //                   of the second MFMA (k-index permutation of the accumulator layout is
 //                   matched on the V side); V^T fragments come from the row-major V tile
 //                   through ds_read_b64_tr_b16 (hardware transpose read).
-//   softmax         exp2 domain, scale folded into one v_fma, raw v_exp_f32; the rescale of O
-//                   is DEFERRED until some row's max grew by > 2^6; the denominators are
-//                   accumulated on the matrix pipe by a V^T tile whose row 0 is all ones.
+//   softmax         exp2 domain, raw v_exp_f32; generic form: scale folded into one v_fma; engine form (PRE): the scale
+//                   lives in the packed to_q weights and -running_max is the C operand of the first MFMA.  The
+//                   rescale of O is DEFERRED until some row's max grew by > 2^6.  Denominators: a V^T tile whose
+//                   row 0 is all ones (matrix pipe), or -- engine form (VSUM) -- v_dot2c_f32_bf16 on the packed P.
 // KV tiles hold NSUB x 32 keys: 64 by default.  The 128-key variant halves the per-tile fixed costs
 // (barrier, max reduction tree, rescale test, loader address math) but loses a wave per SIMD and
-// measured slower (profiles/r01_probe_attention_kv128.log); it is kept behind MVD_ATTN_KV128=1.  K/V tiles are double buffered in LDS;
-// global loads for tile t+1 are issued before the MFMAs of tile t and written after them.
+// measured slower (profiles/r01_probe_attention_kv128.log); it is kept behind MVD_ATTN_KV128=1.  K/V tiles are double
+// buffered in LDS; tile t+1 is fetched under the MFMAs of tile t: by LDS-DMA in the engine's form (DMA), through
+// registers (global_load before the MFMAs, ds_write after them) in the others.
+// The engine's kernel is attn_kernel<4, 2, PRE, DMA, VSUM>: 4 waves x 32 queries, 123 VGPRs, four workgroups per CU,
+// workgroups dealt to the XCDs so that all query blocks of a (batch, head) pair share one L2 (attn_block).
 #include <stdlib.h>
 #include "kernels.h"
 
