@@ -246,6 +246,27 @@ def test_attention_prescaled_cfg4_shape(ops):
     close(got, want, what="prescaled attention 5x4096x4096")
 
 
+@pytest.mark.parametrize("heads,nq,nk,strided", [(5, 4096, 77, False), (5, 1000, 333, False), (10, 1024, 1024, True), (5, 2050, 65, True)])
+def test_attention_engine_form_ragged_and_strided(ops, heads, nq, nk, strided):
+    """The engine's attention kernel (prescaled q, LDS-DMA K/V staging, dot2c denominators, four waves per SIMD, XCD-aware block
+    order) on ragged key / query counts -- keys >= nk reach the kernel as buffer-range zeros and must be masked -- and on K/V
+    that are column slices of a wider fused buffer (row stride 4C, as the q|k|v|q_ref GEMM output is consumed in place)."""
+    from mvd_amd.packing import QSCALE
+    C = heads * 64
+    B = 32 if nq * nk <= 1024 * 1024 else 16
+    q = grnd(B, nq, C, seed=81)
+    if strided:
+        fused = grnd(B, nk, 4 * C, seed=82)
+        k, v = fused[:, :, C:2 * C], fused[:, :, 2 * C:3 * C]
+    else:
+        k, v = grnd(B, nk, C, seed=82), grnd(B, nk, C, seed=83)
+    qs = (q.float() * QSCALE).to(torch.bfloat16)
+    got = ops.attention(qs, k, v, heads, scale=0.0)
+    assert ops.last_attention_plan()["waves"] == 4, ops.last_attention_plan()
+    want = _sdpa_ref(qs.float() / QSCALE, k.contiguous(), v.contiguous(), heads)
+    close(got, want, what=f"engine-form attention {heads}x{nq}x{nk} strided={strided}")
+
+
 # ------------------------------------------------------------------------------- norms at B = 32
 @pytest.mark.parametrize("hw,c0,c1,silu", [(4096, 320, 0, True), (4096, 640, 320, True), (4096, 320, 320, True), (1024, 640, 0, False),
                                            (1024, 640, 320, True), (1024, 1280, 640, True), (256, 1280, 1280, True), (64, 1280, 0, True)])
