@@ -199,8 +199,10 @@ def main():
         pairs = args.pairs
 
     # ---- model: rank 0 creates the synthetic weights, every rank packs buffers, one RCCL broadcast
+    # (dedup_encoder_weights=False: the synthetic image-encoder weights differ from the base UNet's, as a trained checkpoint's
+    #  do -- and the all-zero placeholders of ranks > 0 must not be "de-duplicated" into a different arena layout than rank 0's)
     model = MultiViewUNet(None, unet_config=UNetConfig.sd21(), init="empty", img_ref_scale=0.3,
-                          cam_modulation_strength=0.2, cache_reference=args.cached).to(dev)
+                          cam_modulation_strength=0.2, cache_reference=args.cached, dedup_encoder_weights=False).to(dev)
     model.eval()
     model.use_hip_graph = args.graph
     if rank == 0:

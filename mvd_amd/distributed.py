@@ -66,6 +66,22 @@ def broadcast_arenas(arenas: Iterable[torch.Tensor], src: int = 0, bucket_bytes:
     so few large messages; slices rather than one call keep the transfers pipelined with each other's completion)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return dict(bytes=0, seconds=0.0, buckets=0)
+    arenas = list(arenas)
+    # Every rank must hold the same layout: a mismatch (e.g. one rank de-duplicated the encoder weights and another did not)
+    # would otherwise surface as a transport abort or a hang in the middle of the data broadcast.  One tiny all-gather first.
+    dev = arenas[0].device if arenas else torch.device("cpu")
+    sig = torch.zeros(16, dtype=torch.int64, device=dev)
+    sig[0] = len(arenas)
+    for i, a in enumerate(arenas[:7]):
+        sig[1 + 2 * i], sig[2 + 2 * i] = a.numel(), a.element_size()
+    sigs = [torch.zeros_like(sig) for _ in range(dist.get_world_size())]
+    dist.all_gather(sigs, sig)
+    ref = sigs[src].tolist()
+    for r, s_ in enumerate(sigs):
+        if s_.tolist() != ref:
+            raise RuntimeError(f"weight arena layout differs between rank {src} {ref[:1 + 2 * ref[0]]} and rank {r} "
+                               f"{s_.tolist()[:1 + 2 * int(s_[0])]}: every rank must pack the same slots "
+                               f"(same config, adapter / camera / encoder-sharing choices) before the broadcast")
     t0 = time.perf_counter()
     total = nb = 0
     cuda = False

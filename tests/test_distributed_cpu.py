@@ -90,6 +90,32 @@ def test_gloo_engine_weight_broadcast_world2():
     assert dict(ret) == {0: True, 1: True}
 
 
+def _mismatch_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    D.init_from_env("gloo")
+    _, mine = _engine_weights(rank)
+    if rank == 1:
+        del mine[1]["enc.w"]          # e.g. this rank de-duplicated its encoder weights and rank 0 did not
+    eng = _FakeEngine(mine)
+    try:
+        D.broadcast_engine_weights(eng, 0, bucket_bytes=4096)
+        ret[rank] = "no error"
+    except RuntimeError as e:
+        ret[rank] = "layout differs" in str(e)
+    D.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_gloo_weight_broadcast_rejects_mismatched_layouts():
+    """Ranks whose packed arenas differ (the rank-0-random / rank-1-zero encoder de-duplication trap of bench.py) get a clear
+    error on EVERY rank before any payload moves -- not a transport abort in the middle of the broadcast."""
+    world, port = 2, _free_port()
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_mismatch_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
 def test_pack_into_arenas_layout():
     ref, _ = _engine_weights(0)
     flat = {f"{i}/{k}": t for i, d in enumerate(ref) for k, t in d.items()}
