@@ -172,6 +172,8 @@ def main():
     ap.add_argument("--pairs", type=int, default=0, help="override pairs per GPU")
     ap.add_argument("--cached", action="store_true", help="reuse the step-invariant reference K/V (Q5) instead of re-running the encoder")
     ap.add_argument("--graph", action="store_true", help="replay each forward as one hipGraphLaunch (mvd_engine_set_graph); pays at batch 1 only")
+    ap.add_argument("--global-ref-stats", action="store_true",
+                    help="Q2 statistics over ALL ranks' batches (SURVEY 8e mode ii: one 323 KB all-gather per reference pass) instead of per replica")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the determinism / cross-path output screens")
@@ -205,6 +207,8 @@ def main():
                           cam_modulation_strength=0.2, cache_reference=args.cached, dedup_encoder_weights=False).to(dev)
     model.eval()
     model.use_hip_graph = args.graph
+    if args.global_ref_stats:
+        model.reference_stats_group = True
     if rank == 0:
         fill_synthetic_weights(model, 0)
     else:
@@ -313,7 +317,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "pairs_per_gpu": pairs, "global_pairs": total_pairs,
-                       "latent": "64x64x4", "text_tokens": 77, "forward": forward_kind, "hip_graph": bool(args.graph),
+                       "latent": "64x64x4", "text_tokens": 77, "forward": forward_kind, "hip_graph": bool(args.graph), "q2_statistics": "global" if args.global_ref_stats else "replica-local",
                        "gflop_per_pair": round(flops_pair / 1e9, 2), "parallelism": f"dp{world} (pairs sharded by object)",
                        "weights": "synthetic seeded, SD2.1 shapes (865.9M UNet x2 + 99.2M adapter + 19.1M camera)"},
             "roofline": roofline, "cpu_baseline": cpu, "output_check": check, "kernel_src_sha": kernel_source_sha(),

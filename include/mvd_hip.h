@@ -99,6 +99,23 @@ typedef struct {
 
 int mvd_unet_forward(mvd_engine_t* e, const mvd_forward_args_t* args, void* stream);
 
+/* Global Q2 statistics (SURVEY.md 8e mode ii; optional).  The adapter normalises the reference features with statistics
+ * over (batch, channel) per pixel (attention.py:95-103), so a batch sharded over GPUs sees per-shard statistics unless the
+ * shards exchange them.  The reference pass is therefore also available in two halves:
+ *   mvd_engine_reference_encode   runs the image-encoder pass for `args` (uses height, width, text_len, ref_batch,
+ *                                 source_latents, encoder_text), keeps the 16 raw feature maps in the reference cache (bind it
+ *                                 with keep_features = 1) and writes the LOCAL per-pixel pair (mean, M2 = sum of squared
+ *                                 deviations from that mean) over ref_batch x C of every feature to
+ *                                 local_stats[mvd_engine_reference_pixels()][2], features concatenated in encoder order;
+ *   (the host merges the ranks' pairs -- one all-gather of 215 KB at 64x64 -- into mean and k = 0.5 / max(std, 1e-6))
+ *   mvd_engine_reference_finish   normalises with mean_k[pixels][2] = (mean, k) and projects to the adapter K/V.
+ * Afterwards mvd_unet_forward with MVD_USE_IMAGE | MVD_REUSE_REF runs the main pass on that reference.  With one rank the
+ * three calls reproduce the ordinary forward.  There is no counterpart in the reference (its DDP replicas normalise
+ * locally); mvd_amd.distributed.merge_reference_stats is the host side. */
+int64_t mvd_engine_reference_pixels(mvd_engine_t* e, int height, int width);
+int mvd_engine_reference_encode(mvd_engine_t* e, const mvd_forward_args_t* args, float* local_stats, void* stream);
+int mvd_engine_reference_finish(mvd_engine_t* e, const float* mean_k, void* stream);
+
 /* hipGraph replay of whole forwards.  When enabled, a mvd_unet_forward whose argument block (every pointer, shape and flag),
  * bound buffers and starting reference-cache state were seen before is replayed as ONE hipGraphLaunch: the first call with
  * such a key runs normally, the second is stream-captured and instantiated, later ones replay (up to 8 graphs are kept;

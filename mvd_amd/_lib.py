@@ -62,6 +62,9 @@ _SIGS = {
                                              C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "mvd_engine_profile_shapes": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "mvd_engine_set_graph": (C.c_int, [C.c_void_p, C.c_int]),
+    "mvd_engine_reference_pixels": (C.c_int64, [C.c_void_p, C.c_int, C.c_int]),
+    "mvd_engine_reference_encode": (C.c_int, [C.c_void_p, C.POINTER(mvd_forward_args_t), C.c_void_p, C.c_void_p]),
+    "mvd_engine_reference_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mvd_engine_share_encoder_weights": (C.c_int, [C.c_void_p, C.c_int]),
     "mvd_engine_num_features": (C.c_int, [C.c_void_p]),
     "mvd_engine_feature_shape": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),

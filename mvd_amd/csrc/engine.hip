@@ -45,7 +45,8 @@ struct Act {  // NHWC bf16 activation
   int rows() const { return B * H * W; }
 };
 
-struct FeatureInfo { std::string name; int level; int C; int heads; };
+struct FeatureInfo { std::string name; int level; int C; int heads; std::string key; /* weight-slot prefix of the block */ };
+constexpr int MVD_REF_ONLY_INTERNAL = 1 << 30;   // set by mvd_engine_reference_encode only (rejected on the public entry)
 
 }  // namespace
 
@@ -60,6 +61,11 @@ struct mvd_engine {
   std::vector<bf16_t*> refkv;       // per feature: [ref_batch*hw][4C]
   std::vector<bf16_t*> feat_keep;   // per feature: [ref_batch][hw][C] when kept
   int rc_batch = 0, rc_h = 0, rc_w = 0; bool rc_valid = false; bool rc_keep = false;
+  // global Q2 statistics (mvd_engine_reference_encode / _finish): the encoder pass stops before the normalisation
+  float* ref_stats_out = nullptr;   // set only while mvd_engine_reference_encode runs
+  bool rc_pending = false;          // raw features are in feat_keep, waiting for the merged statistics
+  int64_t ref_pixels(int h, int w) const { int64_t n = 0; for (auto& f : feats) n += (int64_t)(h >> f.level) * (w >> f.level); return n; }
+  int64_t feat_pixel_off(int idx) const { int64_t n = 0; for (int i = 0; i < idx; ++i) n += (int64_t)(rc_h >> feats[i].level) * (rc_w >> feats[i].level); return n; }
   float* cam_emb = nullptr; int cam_batch = 0;
   bool share_encoder = false;       // N4: the encoder pass reads weight set 0 (base UNet == image-encoder UNet)
   // hipGraph replay of whole forwards (mvd_engine_set_graph): one instantiated graph per distinct (arguments, cache state)
@@ -278,10 +284,12 @@ std::vector<FeatureInfo> enumerate_features(const mvd_config_t& c) {
   std::vector<FeatureInfo> f;
   const int n = c.num_levels, L = c.layers_per_block;
   for (int i = 0; i + 1 < n; ++i)
-    for (int j = 0; j < L; ++j) f.push_back({"down_block_" + std::to_string(i) + "_attn_" + std::to_string(j), i, c.block_out_channels[i], c.num_heads[i]});
-  f.push_back({"mid_block_attn_0", n - 1, c.block_out_channels[n - 1], c.num_heads[n - 1]});
+    for (int j = 0; j < L; ++j) f.push_back({"down_block_" + std::to_string(i) + "_attn_" + std::to_string(j), i, c.block_out_channels[i], c.num_heads[i],
+                   "down_blocks." + std::to_string(i) + ".attentions." + std::to_string(j)});
+  f.push_back({"mid_block_attn_0", n - 1, c.block_out_channels[n - 1], c.num_heads[n - 1], "mid_block.attentions.0"});
   for (int i = 1; i < n; ++i)
-    for (int j = 0; j <= L; ++j) f.push_back({"up_block_" + std::to_string(i) + "_attn_" + std::to_string(j), n - 1 - i, c.block_out_channels[n - 1 - i], c.num_heads[n - 1 - i]});
+    for (int j = 0; j <= L; ++j) f.push_back({"up_block_" + std::to_string(i) + "_attn_" + std::to_string(j), n - 1 - i, c.block_out_channels[n - 1 - i], c.num_heads[n - 1 - i],
+                   "up_blocks." + std::to_string(i) + ".attentions." + std::to_string(j)});
   return f;
 }
 
@@ -289,6 +297,8 @@ struct PassOpts {
   bool adapter = false;       // add the cross-view attention branch (needs e->refkv)
   bool film = false;          // apply camera FiLM hooks
   bool capture = false;       // encoder pass: produce reference K/V (+ keep features)
+  bool defer_norm = false;    // capture, global-statistics form: per-pixel local (mean, M2) go to `stats`, the features are
+  float* stats = nullptr;     // kept raw and normalisation + K/V projection wait for mvd_engine_reference_finish
   int ref_batch = 0;          // batch of the reference features (Q4 re-chunking)
   const std::unordered_map<std::string, std::pair<float*, float*>>* film_ss = nullptr;  // name -> (scale, shift) [B][dim]
 };
@@ -393,9 +403,13 @@ struct UNetPass {
 
     if (o.capture) {  // encoder pass: reference normalisation (Q2) + adapter K/V for both processors of this feature
       const size_t mk = c.e->tmp.off;
-      bf16_t* rn = c.talloc<bf16_t>((size_t)M * C);
-      if (!c.dry && !c.err) CHECK(mvd_launch_refnorm(out.p, B_, hw, C, rn, c.s));
-      CHECK(c.linear(rn, nullptr, C, 0, M, c.WB(key + ".ref_kv.w", (int64_t)4 * C * C, 0), nullptr, 4 * C, nullptr, 0, c.e->refkv[feat_idx], 4 * C));
+      bf16_t* rn = c.talloc<bf16_t>((size_t)M * C);        // (also sized in the deferred form: _finish needs the same scratch)
+      if (o.defer_norm) {
+        if (!c.dry && !c.err) CHECK(mvd_launch_refstats(out.p, B_, hw, C, o.stats + 2 * c.e->feat_pixel_off(feat_idx), c.s));
+      } else {
+        if (!c.dry && !c.err) CHECK(mvd_launch_refnorm(out.p, B_, hw, C, rn, c.s));
+        CHECK(c.linear(rn, nullptr, C, 0, M, c.WB(key + ".ref_kv.w", (int64_t)4 * C * C, 0), nullptr, 4 * C, nullptr, 0, c.e->refkv[feat_idx], 4 * C));
+      }
       if (c.e->rc_keep && !c.dry && !c.err)
         CHECK((int)hipMemcpyAsync(c.e->feat_keep[feat_idx], out.p, (size_t)M * C * sizeof(bf16_t), hipMemcpyDeviceToDevice, c.s));
       c.e->tmp.off = mk;
@@ -634,9 +648,12 @@ int forward_impl(mvd_engine* e, const mvd_forward_args_t& a, hipStream_t s, bool
   if (a.batch <= 0 || a.height <= 0 || a.width <= 0 || a.text_len <= 0) { mvd_set_error("forward: bad shape"); return -1; }
   const int div = 1 << (cfg.num_levels - 1);
   if (a.height % div || a.width % div) { mvd_set_error("forward: latent %dx%d must be divisible by %d", a.height, a.width, div); return -1; }
-  const bool use_cam = a.flags & MVD_USE_CAMERA, use_img = a.flags & MVD_USE_IMAGE, reuse = a.flags & MVD_REUSE_REF;
+  // ref_only: mvd_engine_reference_encode -- the reference pass alone, normalisation deferred (global Q2 statistics)
+  const bool ref_only = a.flags & MVD_REF_ONLY_INTERNAL;
+  const bool use_cam = (a.flags & MVD_USE_CAMERA) && !ref_only, use_img = a.flags & MVD_USE_IMAGE, reuse = a.flags & MVD_REUSE_REF;
+  if (ref_only && (!use_img || reuse)) { mvd_set_error("reference_encode: needs MVD_USE_IMAGE without MVD_REUSE_REF"); return -1; }
   if (!dry) {
-    if (!a.sample || !a.timesteps || !a.text || !a.out) { mvd_set_error("forward: null sample/timesteps/text/out"); return -1; }
+    if (!ref_only && (!a.sample || !a.timesteps || !a.text || !a.out)) { mvd_set_error("forward: null sample/timesteps/text/out"); return -1; }
     if (use_cam && (!a.source_camera || !a.target_camera || !a.fourier_proj || (a.cam_rows != 3 && a.cam_rows != 4))) { mvd_set_error("forward: camera inputs missing"); return -1; }
     if (use_img && !reuse && (!a.source_latents || !a.encoder_text || a.ref_batch <= 0)) { mvd_set_error("forward: image-conditioning inputs missing"); return -1; }
     if (!e->ws_ptr) { mvd_set_error("forward: workspace not bound"); return -1; }
@@ -655,7 +672,7 @@ int forward_impl(mvd_engine* e, const mvd_forward_args_t& a, hipStream_t s, bool
 
   // ---- persistent reference cache layout
   if (use_img) {
-    const bool keep = a.flags & MVD_KEEP_FEATURES;
+    const bool keep = (a.flags & MVD_KEEP_FEATURES) || ref_only;
     if (reuse) {
       if (!e->rc_valid || e->rc_batch != a.ref_batch || e->rc_h != H || e->rc_w != Wd) { mvd_set_error("forward: MVD_REUSE_REF without a matching cached reference"); return -1; }
     } else {
@@ -670,7 +687,7 @@ int forward_impl(mvd_engine* e, const mvd_forward_args_t& a, hipStream_t s, bool
       }
       if (e->persist.overflow()) { mvd_set_error("forward: reference cache too small (%zu > %zu bytes)", e->persist.high, e->persist.cap); return -4; }
       e->rc_keep = keep; e->rc_batch = a.ref_batch; e->rc_h = H; e->rc_w = Wd;
-      if (!dry) e->rc_valid = false;
+      if (!dry) { e->rc_valid = false; e->rc_pending = false; }
     }
   }
 
@@ -696,10 +713,16 @@ int forward_impl(mvd_engine* e, const mvd_forward_args_t& a, hipStream_t s, bool
       CHECK(mvd_launch_im2col_in(a.source_latents, Br, cfg.in_channels, H, Wd, nullptr, nullptr, 0, xin.p, s));
     }
     PassOpts po; po.capture = true; po.ref_batch = Br;
+    po.defer_norm = ref_only; po.stats = e->ref_stats_out;
     UNetPass pass{c, cfg, po, Br, H, Wd, L, tx, tproj};
     CHECK(pass.run(xin, nullptr));
-    if (!dry) e->rc_valid = true;
+    if (!dry) { e->rc_valid = !ref_only; e->rc_pending = ref_only; }
     e->tmp.off = tm; e->act.off = am;   // encoder activations are dead; reuse their memory
+  }
+  if (ref_only) {
+    if (c.err) return c.err;
+    if (!dry && (e->tmp.high + e->act.high > (size_t)e->ws_bytes)) { mvd_set_error("reference_encode: workspace too small"); return -4; }
+    return 0;
   }
 
   // ---- main pass
@@ -720,6 +743,26 @@ int forward_impl(mvd_engine* e, const mvd_forward_args_t& a, hipStream_t s, bool
   if (c.err) return c.err;
   if (!dry && (e->tmp.high + e->act.high > (size_t)e->ws_bytes)) { mvd_set_error("forward: workspace too small"); return -4; }
   return 0;
+}
+
+// Second half of the global-statistics path: normalise the kept raw features with the merged per-pixel (mean, k) and
+// project them to the adapter K/V -- the same two launches per feature the encoder pass makes in the local form.
+int reference_finish_impl(mvd_engine* e, const float* mean_k, hipStream_t s, bool dry) {
+  e->tmp.dry = dry;
+  e->tmp.off = e->tmp.high = 0;
+  Ctx c{e, s, 0, dry};
+  c.set = 0;                                         // the adapter's ref_kv weights live with the base set
+  for (size_t i = 0; i < e->feats.size(); ++i) {
+    const int lv = e->feats[i].level, C = e->feats[i].C;
+    const int hw = (e->rc_h >> lv) * (e->rc_w >> lv), M = e->rc_batch * hw;
+    const std::string& key = e->feats[i].key;
+    const size_t mk = e->tmp.off;
+    bf16_t* rn = c.talloc<bf16_t>((size_t)M * C);
+    if (!dry && !c.err) CHECK(mvd_launch_refapply(e->feat_keep[i], e->rc_batch, hw, C, mean_k + 2 * e->feat_pixel_off((int)i), rn, s));
+    CHECK(c.linear(rn, nullptr, C, 0, M, c.WB(key + ".ref_kv.w", (int64_t)4 * C * C, 0), nullptr, 4 * C, nullptr, 0, e->refkv[i], 4 * C));
+    e->tmp.off = mk;
+  }
+  return c.err;
 }
 
 }  // namespace
@@ -814,12 +857,54 @@ int mvd_engine_bind_workspace(mvd_engine_t* e, void* ws, int64_t ws_bytes, void*
   e->ws_ptr = ws; e->ws_bytes = ws_bytes;
   e->rc_ptr = refcache; e->rc_bytes = refcache_bytes;
   e->persist.base = (char*)refcache; e->persist.cap = (size_t)(refcache ? refcache_bytes : 0);
-  e->rc_valid = false;
+  e->rc_valid = false; e->rc_pending = false;
+  return 0;
+}
+
+int64_t mvd_engine_reference_pixels(mvd_engine_t* e, int height, int width) {
+  if (!e || height <= 0 || width <= 0) { mvd_set_error("reference_pixels: bad argument"); return -1; }
+  return e->ref_pixels(height, width);
+}
+
+int mvd_engine_reference_encode(mvd_engine_t* e, const mvd_forward_args_t* args, float* local_stats, void* stream) {
+  if (!e || !args || !local_stats) { mvd_set_error("reference_encode: null argument"); return -1; }
+  e->drop_graphs();
+  mvd_forward_args_t a = *args;
+  a.flags = (a.flags & ~MVD_REUSE_REF) | MVD_USE_IMAGE | MVD_KEEP_FEATURES | MVD_REF_ONLY_INTERNAL;
+  if (a.batch <= 0) a.batch = a.ref_batch;
+  int r = forward_impl(e, a, nullptr, true);
+  e->rc_valid = false; e->rc_pending = false;
+  if (r) return r;
+  const size_t act_bytes = (e->act.high + 255) & ~size_t(255);
+  if (!e->ws_ptr || act_bytes + e->tmp.high > (size_t)e->ws_bytes) {
+    mvd_set_error("reference_encode: workspace too small: need %zu bytes, bound %lld", act_bytes + e->tmp.high, (long long)e->ws_bytes);
+    return -4;
+  }
+  e->act.base = (char*)e->ws_ptr; e->act.cap = act_bytes;
+  e->tmp.base = (char*)e->ws_ptr + act_bytes; e->tmp.cap = (size_t)e->ws_bytes - act_bytes;
+  e->ref_stats_out = local_stats;
+  r = forward_impl(e, a, (hipStream_t)stream, false);
+  e->ref_stats_out = nullptr;
+  return r;
+}
+
+int mvd_engine_reference_finish(mvd_engine_t* e, const float* mean_k, void* stream) {
+  if (!e || !mean_k) { mvd_set_error("reference_finish: null argument"); return -1; }
+  if (!e->rc_pending) { mvd_set_error("reference_finish: no pending reference (call mvd_engine_reference_encode first)"); return -1; }
+  e->drop_graphs();
+  int r = reference_finish_impl(e, mean_k, nullptr, true);
+  if (r) return r;
+  if (!e->ws_ptr || e->tmp.high > (size_t)e->ws_bytes) { mvd_set_error("reference_finish: workspace too small (%zu > %lld bytes)", e->tmp.high, (long long)e->ws_bytes); return -4; }
+  e->tmp.base = (char*)e->ws_ptr; e->tmp.cap = (size_t)e->ws_bytes;
+  r = reference_finish_impl(e, mean_k, (hipStream_t)stream, false);
+  if (r) return r;
+  e->rc_pending = false; e->rc_valid = true;
   return 0;
 }
 
 int mvd_unet_forward(mvd_engine_t* e, const mvd_forward_args_t* args, void* stream) {
   if (!e || !args) { mvd_set_error("forward: null argument"); return -1; }
+  if (args->flags & MVD_REF_ONLY_INTERNAL) { mvd_set_error("forward: unknown flag bits 0x%x", args->flags); return -1; }
   // size the two arenas for this shape with a dry run (pure host arithmetic), then run for real
   const bool valid = e->rc_valid;
   std::vector<bf16_t*> kv = e->refkv, fk = e->feat_keep;

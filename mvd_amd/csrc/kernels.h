@@ -99,6 +99,8 @@ int mvd_launch_layernorm(const bf16_t* x, int rows, int c, float eps, const floa
                          bf16_t* y, hipStream_t s);
 // Q2 reference normalisation: per pixel over (batch, channel), unbiased std, clamp 1e-6, *0.5
 int mvd_launch_refnorm(const bf16_t* x, int batch, int hw, int c, bf16_t* y, hipStream_t s);
+int mvd_launch_refstats(const bf16_t* x, int batch, int hw, int c, float* stats /*[hw][2]: mean, M2*/, hipStream_t s);
+int mvd_launch_refapply(const bf16_t* x, int batch, int hw, int c, const float* mean_k /*[hw][2]*/, bf16_t* y, hipStream_t s);
 
 // ---------------------------------------------------------------- elementwise / small ops
 // NCHW fp32 -> NHWC bf16 with optional FiLM (scale/shift fp32 [batch][c])

@@ -399,6 +399,59 @@ __global__ __launch_bounds__(256) void refnorm_kernel(const bf16_t* __restrict__
   }
 }
 
+// Q2 with statistics that span several GPUs (SURVEY.md 8e mode ii): the same arithmetic cut in two.  refstats writes, per
+// pixel, the LOCAL mean and the sum of squared deviations from it (M2) over (batch, channel); the host merges the ranks'
+// pairs (Chan's parallel form -- no E[x^2] - mean^2 cancellation) into (mean, k = 0.5 / max(std, 1e-6)) and refapply
+// normalises with those.  With one rank the pair (refstats -> merge -> refapply) reproduces refnorm_kernel.
+__global__ __launch_bounds__(256) void refstats_kernel(const bf16_t* __restrict__ x, int batch, int hw, int c, float* __restrict__ stats) {
+  __shared__ float red[8];
+  const int p = blockIdx.x;
+  const int vec = c >> 3;
+  const int total = batch * vec;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  auto block_sum = [&](float v) -> float {
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+  };
+  float s = 0.f;
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int b = e / vec, v = e % vec;
+    float f[8];
+    unpack8(*reinterpret_cast<const u32x4*>(x + ((size_t)b * hw + p) * c + v * 8), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += f[j];
+  }
+  const float mean = block_sum(s) / ((float)batch * (float)c);
+  float q = 0.f;
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int b = e / vec, v = e % vec;
+    float f[8];
+    unpack8(*reinterpret_cast<const u32x4*>(x + ((size_t)b * hw + p) * c + v * 8), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float d = f[j] - mean; q = fmaf(d, d, q); }
+  }
+  const float m2 = block_sum(q);
+  if (threadIdx.x == 0) { stats[2 * p] = mean; stats[2 * p + 1] = m2; }
+}
+
+__global__ __launch_bounds__(256) void refapply_kernel(const bf16_t* __restrict__ x, int batch, int hw, int c,
+                                                       const float* __restrict__ mean_k, bf16_t* __restrict__ y) {
+  const int vec = c >> 3;
+  const long total = (long)batch * hw * vec;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int p = (int)((e / vec) % hw);
+    const float mean = mean_k[2 * p], k = mean_k[2 * p + 1];
+    float f[8];
+    unpack8(*reinterpret_cast<const u32x4*>(x + e * 8), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (f[j] - mean) * k;
+    *reinterpret_cast<u32x4*>(y + e * 8) = pack8(f);
+  }
+}
+
 // ---------------------------------------------------------------- fp32 row LayerNorm (camera MLPs)
 __global__ __launch_bounds__(256) void ln_f32_kernel(const float* __restrict__ x, int c, float eps,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -516,6 +569,18 @@ int mvd_launch_layernorm(const bf16_t* x, int rows, int c, float eps, const floa
   return check_launch("layernorm");
 }
 
+int mvd_launch_refstats(const bf16_t* x, int batch, int hw, int c, float* stats, hipStream_t s) {
+  if (!x || !stats || batch <= 0 || hw <= 0 || c <= 0 || (c % 8)) { mvd_set_error("refstats: bad arguments"); return -1; }
+  hipLaunchKernelGGL(refstats_kernel, dim3(hw), dim3(256), 0, s, x, batch, hw, c, stats);
+  return check_launch("refstats");
+}
+int mvd_launch_refapply(const bf16_t* x, int batch, int hw, int c, const float* mean_k, bf16_t* y, hipStream_t s) {
+  if (!x || !y || !mean_k || batch <= 0 || hw <= 0 || c <= 0 || (c % 8)) { mvd_set_error("refapply: bad arguments"); return -1; }
+  const long total = (long)batch * hw * (c >> 3);
+  long grid = (total + 255) / 256; if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(refapply_kernel, dim3((unsigned)grid), dim3(256), 0, s, x, batch, hw, c, mean_k, y);
+  return check_launch("refapply");
+}
 int mvd_launch_refnorm(const bf16_t* x, int batch, int hw, int c, bf16_t* y, hipStream_t s) {
   if (!x || !y || batch <= 0 || hw <= 0 || c <= 0 || (c % 8)) { mvd_set_error("refnorm: bad arguments"); return -1; }
   hipLaunchKernelGGL(refnorm_kernel, dim3(hw), dim3(256), 0, s, x, batch, hw, c, y);

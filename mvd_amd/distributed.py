@@ -156,6 +156,44 @@ def broadcast_engine_weights(engine, src: int = 0, bucket_bytes: int = 256 << 20
     return broadcast_arenas(engine._arenas.values(), src, bucket_bytes)
 
 
+def merge_reference_stats(local: torch.Tensor, group=None) -> torch.Tensor:
+    """Global Q2 statistics (SURVEY.md 8e mode ii): merge the ranks' per-pixel ``(n, mean, M2)`` rows
+    (``Engine.reference_encode``) into ``(mean, k)`` with ``k = 0.5 / max(std, 1e-6)`` and the UNBIASED std over all ranks'
+    ``n`` samples (attention.py:95-103 on the unsharded batch).  ONE all-gather of ``pixels * 12`` bytes (323 KB at 64x64);
+    the merge is Chan's parallel update in fp64, in rank order, so every rank computes bit-identical results.  Without a
+    process group (or world size 1) it just finishes the local statistics."""
+    if local.dim() != 2 or local.shape[1] != 3:
+        raise ValueError("merge_reference_stats expects [pixels][3] rows (n, mean, M2)")
+    parts = [local]
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        world = dist.get_world_size(group)
+        on_host = local.is_cuda and dist.get_backend(group) == "gloo"       # gloo: stage the 323 KB through the host
+        src = local.cpu() if on_host else local.contiguous()
+        parts = [torch.empty_like(src) for _ in range(world)]
+        dist.all_gather(parts, src, group=group)
+        parts = [p.to(local.device) for p in parts]
+    return merge_stat_parts(parts)
+
+
+def merge_stat_parts(parts: Sequence[torch.Tensor]) -> torch.Tensor:
+    """The arithmetic of ``merge_reference_stats`` on the already gathered per-rank ``[pixels][3]`` rows, in list order."""
+    n = torch.zeros_like(parts[0][:, 0], dtype=torch.float64)
+    mean = torch.zeros_like(n)
+    m2 = torch.zeros_like(n)
+    for p in parts:
+        pn, pm, pq = p[:, 0].double(), p[:, 1].double(), p[:, 2].double()
+        tot = n + pn
+        delta = pm - mean
+        mean = mean + delta * pn / tot
+        m2 = m2 + pq + delta * delta * n * pn / tot
+        n = tot
+    # the last step in fp32, as refnorm_kernel does it (var = M2 / (n - 1); k = 0.5 / max(sqrt(var), 1e-6)): with ONE part
+    # the result is then bit-identical to the fused reference pass
+    mean, m2, n = mean.float(), m2.float(), n.float()
+    k = 0.5 / (m2 / (n - 1.0)).sqrt().clamp_min(1e-6)
+    return torch.stack([mean, k], dim=1).contiguous()
+
+
 def max_over_ranks(value: float, device) -> float:
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return value

@@ -212,6 +212,52 @@ class MVDEngine:
             self._ref_valid = (B, H, W, Lt, ref_batch)
         return out
 
+    # ------------------------------------------------------------------ reference pass in two halves (global Q2 statistics)
+    def reference_encode(self, source_latents: torch.Tensor, encoder_text: torch.Tensor, main_batch: int) -> torch.Tensor:
+        """First half (``mvd_engine_reference_encode``): the image-encoder pass on ``source_latents``; the raw features stay in
+        the engine, the LOCAL per-pixel statistics come back as ``[pixels][3]`` fp32 rows (n, mean, M2) with n = ref_batch * C
+        of the pixel's feature -- what ``distributed.merge_reference_stats`` exchanges.  ``main_batch`` is the batch of the
+        forwards that will follow (the workspace is bound once for both)."""
+        for t in (source_latents, encoder_text):
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                raise L.MvdError("engine.reference_encode expects contiguous fp32 CUDA tensors")
+        Br, _, H, W = source_latents.shape
+        Lt = encoder_text.shape[1]
+        if encoder_text.shape[0] != Br:
+            raise L.MvdError("image conditioning needs encoder_text with the reference batch")
+        self._last_ref_batch = Br
+        self._ensure_workspace(main_batch, H, W, Lt, Br, True)
+        npix = L.lib().mvd_engine_reference_pixels(self._h, H, W)
+        stats = torch.empty(npix, 2, dtype=torch.float32, device=self.device)
+        a = L.mvd_forward_args_t()
+        a.batch, a.height, a.width, a.text_len = main_batch, H, W, Lt
+        a.source_latents, a.encoder_text = source_latents.data_ptr(), encoder_text.data_ptr()
+        a.ref_batch, a.flags = Br, L.MVD_USE_IMAGE
+        L.call("mvd_engine_reference_encode", self._h, C.byref(a), _ptr(stats), _stream())
+        self._ref_valid = None
+        self._ref_pending = (main_batch, H, W, Lt, Br)
+        n = torch.empty(npix, dtype=torch.float32, device=self.device)
+        off = 0
+        c_, h_, w_ = C.c_int(), C.c_int(), C.c_int()
+        for i in range(L.lib().mvd_engine_num_features(self._h)):
+            L.call("mvd_engine_feature_shape", self._h, i, C.byref(c_), C.byref(h_), C.byref(w_))
+            n[off:off + h_.value * w_.value] = float(Br * c_.value)
+            off += h_.value * w_.value
+        return torch.cat([n[:, None], stats], dim=1)
+
+    def reference_finish(self, mean_k: torch.Tensor) -> None:
+        """Second half (``mvd_engine_reference_finish``): ``mean_k`` = ``[pixels][2]`` fp32 (mean, 0.5 / max(std, 1e-6)) after the
+        merge.  Afterwards ``forward(..., reuse_ref=True, keep_features=True)`` runs on this reference."""
+        pend = getattr(self, "_ref_pending", None)
+        if pend is None:
+            raise L.MvdError("reference_finish without a pending reference_encode")
+        npix = L.lib().mvd_engine_reference_pixels(self._h, pend[1], pend[2])
+        if not (mean_k.is_cuda and mean_k.dtype == torch.float32 and mean_k.is_contiguous() and tuple(mean_k.shape) == (npix, 2)):
+            raise L.MvdError(f"reference_finish expects a contiguous fp32 CUDA tensor [{npix}, 2]")
+        L.call("mvd_engine_reference_finish", self._h, _ptr(mean_k), _stream())
+        self._ref_pending = None
+        self._ref_valid = pend
+
     def set_graph(self, enable: bool) -> None:
         """Replay repeated forwards (same shapes / flags) as one hipGraphLaunch each (``mvd_engine_set_graph``)."""
         L.call("mvd_engine_set_graph", self._h, int(bool(enable)))

@@ -159,6 +159,10 @@ class MultiViewUNet(nn.Module):
         self._dirty = True
         self._ref_key = None
         self._ref_hold = None              # strong references to the tensors _ref_key was computed from
+        # Q2 statistics across data-parallel shards: None = replica-local (what the reference's DDP replicas
+        # compute); True = the default process group, or a torch.distributed group = statistics over ALL ranks' batches
+        # (one 323 KB all-gather per reference pass), which makes the sharded result equal the unsharded one
+        self.reference_stats_group = None
         self.current_camera_embedding = None
         self.fourier_projection = None     # set to a (cam_dim, 6*nfreq) tensor to pin Q1's per-call random matrix
 
@@ -298,13 +302,21 @@ class MultiViewUNet(nn.Module):
             # object denoised right after the first would otherwise hit the first object's K/V).
             key = (source_image_latents.data_ptr(), source_image_latents._version, tuple(source_image_latents.shape),
                    encoder_hidden_states.data_ptr(), encoder_hidden_states._version, tuple(encoder_hidden_states.shape), B)
+            glob = self.reference_stats_group is not None
             if (self.cache_reference and self._ref_key == key
                     and eng.reference_cache_valid(B, x.shape[2], x.shape[3], text.shape[1], bs)):
-                img = dict(reuse_ref=True)
+                img = dict(reuse_ref=True, keep_features=glob)
             else:
                 img = dict(source_latents=self._f32(source_image_latents, dev), encoder_text=enc_text.contiguous())
                 self._ref_key = key
                 self._ref_hold = (source_image_latents, encoder_hidden_states) if self.cache_reference else None
+                if glob:
+                    # SURVEY.md 8e mode (ii): the reference pass in two halves around ONE all-gather of per-pixel statistics
+                    from .distributed import merge_reference_stats
+                    group = None if self.reference_stats_group is True else self.reference_stats_group
+                    local = eng.reference_encode(img["source_latents"], img["encoder_text"], B)
+                    eng.reference_finish(merge_reference_stats(local, group))
+                    img = dict(reuse_ref=True, keep_features=True)
         out = eng.forward(x, t, text, **cam, **img)
         if cam:
             self.current_camera_embedding = eng.camera_embedding(cam["target_camera"].shape[0])

@@ -116,6 +116,62 @@ def test_gloo_weight_broadcast_rejects_mismatched_layouts():
     assert dict(ret) == {0: True, 1: True}
 
 
+def _q2_shard(rank):
+    """Reference features of one rank: two 'feature maps' (C 64 / 128) with 6 + 3 pixels, UNEQUAL batches per rank and a
+    large common offset (the cancellation case a sum / sum-of-squares exchange would lose)."""
+    g = torch.Generator().manual_seed(100 + rank)
+    b = 3 + 2 * rank
+    return [torch.randn(b, 64, 6, generator=g) * 0.7 + 40.0, torch.randn(b, 128, 3, generator=g) * 2.0 - 5.0]
+
+
+def _q2_local(feats):
+    rows = []
+    for f in feats:                                              # [b][C][pixels] -> per pixel (n, mean, M2) over (b, C)
+        n = f.shape[0] * f.shape[1]
+        x = f.permute(2, 0, 1).reshape(f.shape[2], n)
+        mean = x.mean(1)
+        rows.append(torch.stack([torch.full_like(mean, float(n)), mean, ((x - mean[:, None]) ** 2).sum(1)], 1))
+    return torch.cat(rows)
+
+
+def _q2_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    D.init_from_env("gloo")
+    got = D.merge_reference_stats(_q2_local(_q2_shard(rank)))
+    # the reference's arithmetic on the UNSHARDED batch (attention.py:95-103: mean / unbiased std over dims (0, 1), clamp, x0.5)
+    full = [torch.cat([_q2_shard(r)[i] for r in range(world)]).double() for i in range(2)]
+    mean = torch.cat([f.mean(dim=(0, 1)) for f in full])
+    k = torch.cat([0.5 / f.std(dim=(0, 1)).clamp_min(1e-6) for f in full])
+    ok = torch.allclose(got[:, 0].double(), mean, rtol=1e-6, atol=0) and torch.allclose(got[:, 1].double(), k, rtol=1e-5, atol=0)
+    gathered = [torch.empty_like(got) for _ in range(world)]
+    torch.distributed.all_gather(gathered, got)
+    ok = ok and all(torch.equal(g_, got) for g_ in gathered)           # every rank holds bit-identical statistics
+    D.barrier()
+    ret[rank] = bool(ok)
+    torch.distributed.destroy_process_group()
+
+
+def test_gloo_global_reference_statistics_world2():
+    """SURVEY.md 8e mode (ii): the merged per-pixel (mean, k) of two ranks' shards equal the statistics of the unsharded
+    batch, with unequal shard sizes and a large common offset; all ranks end with the same bits."""
+    world, port = 2, _free_port()
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_q2_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+def test_reference_statistics_merge_single_process():
+    """Without a process group the merge only finishes the local statistics (n, mean, M2) -> (mean, 0.5 / max(std, 1e-6))."""
+    feats = _q2_shard(0)
+    got = D.merge_reference_stats(_q2_local(feats))
+    mean = torch.cat([f.mean(dim=(0, 1)) for f in feats])
+    k = torch.cat([0.5 / f.std(dim=(0, 1)).clamp_min(1e-6) for f in feats])
+    assert torch.allclose(got[:, 0], mean, rtol=1e-6) and torch.allclose(got[:, 1], k, rtol=1e-5)
+    const = torch.tensor([[8.0, 1.5, 0.0]])                       # zero variance: the clamp, not a division by zero
+    assert D.merge_reference_stats(const)[0].tolist() == [1.5, 0.5 / 1e-6]
+
+
 def test_pack_into_arenas_layout():
     ref, _ = _engine_weights(0)
     flat = {f"{i}/{k}": t for i, d in enumerate(ref) for k, t in d.items()}
