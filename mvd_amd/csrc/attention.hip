@@ -24,6 +24,10 @@
 // measured slower (profiles/r01_probe_attention_kv128.log); it is kept behind MVD_ATTN_KV128=1.  K/V tiles are double
 // buffered in LDS; tile t+1 is fetched under the MFMAs of tile t: by LDS-DMA in the engine's form (DMA), through
 // registers (global_load before the MFMAs, ds_write after them) in the others.
+// The engine form is bound by the vector-issue port (per 64-key tile and wave: 32 v_exp_f32 at 8 issue cycles, 16 converts,
+// 16 dot products, 18 max, 16 MFMAs at 8 -- against 512 matrix cycles), so everything else was taken off that port: the
+// score tiles start from the live -max tile without a copy (mfma_from), the DMA destinations are scalar, and the two halves
+// of a row exchange their maxima only inside the rare rescale branch (113 -> 92 non-MFMA vector instructions per tile, -2.4 %).
 // The engine's kernel is attn_kernel<4, 2, PRE, DMA, VSUM>: 4 waves x 32 queries, 123 VGPRs, four workgroups per CU,
 // workgroups dealt to the XCDs so that all query blocks of a (batch, head) pair share one L2 (attn_block).
 #include <stdlib.h>
@@ -48,6 +52,18 @@ MVD_DEVINL float pair_other(float x, float& own) {
   const unsigned r0 = r[0], r1 = r[1];
   own = __builtin_bit_cast(float, r0);
   return __builtin_bit_cast(float, r1);
+}
+// D = A.B + C with C a register tile that STAYS LIVE (the -running_max tile that starts every score tile).  Through the builtin
+// hipcc ties D to C and first copies C (8 v_mov_b64 per 32x32 tile, on the vector-issue port that bounds this kernel); here D
+// is its own early-clobber tile.  The hazard recognizer does not see an MFMA in an asm statement, so the statement carries
+// its own wait states for "VALU wrote C" (s_nop 1); operands that come from LDS are still covered by the compiler's
+// s_waitcnt (register operands of an asm are tracked), and the next accumulate into D is the same opcode on exactly the
+// same vDst (back-to-back dependent MFMAs need no software wait states).  The LAST MFMA into D is always a builtin, so the
+// MFMA -> VALU read distance of the softmax is the compiler's.
+MVD_DEVINL f32x16 mfma_from(bf16x8 a, bf16x8 b, const f32x16& c) {
+  f32x16 d;
+  asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
 }
 MVD_DEVINL float pair_max(float x) { float o; const float p = pair_other(x, o); return fmaxf(o, p); }
 MVD_DEVINL float pair_sum(float x) { float o; const float p = pair_other(x, o); return o + p; }
@@ -134,8 +150,11 @@ __global__ __launch_bounds__(64 * NW, VSUM ? 4 : ((NW == 4 && NSUB == 2) ? 3 : 2
   const unsigned dma_ko = (unsigned)ld_row * (unsigned)ldk * 2u + ((ld_kc ^ ((ld_row >> 1) & 7)) << 4);
   const unsigned dma_vo = (unsigned)ld_row * (unsigned)ldv * 2u + ((ld_kc ^ (((ld_row >> 1) & 1) << 2)) << 4);
   auto dma_tile = [&](int kb, int st) {            // tile kb -> stage st (lane-linear LDS image, swizzled source chunk)
-    unsigned char* dk = smem + st * TILE_BYTES + wave * 1024;
-    unsigned char* dv = smem + (2 + st) * TILE_BYTES + wave * 1024;
+    // (the wave index as a SCALAR: the LDS destination of a DMA goes through M0, and a vector-derived address costs a v_add +
+    //  v_readfirstlane per instruction on the vector-issue port this kernel is bound by)
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    unsigned char* dk = smem + st * TILE_BYTES + wave_s * 1024;
+    unsigned char* dv = smem + (2 + st) * TILE_BYTES + wave_s * 1024;
 #pragma unroll
     for (int i = 0; i < LD_IT; ++i) {
       const int row0 = kb * KV_TILE + i * (NT / 8);
@@ -226,8 +245,12 @@ __global__ __launch_bounds__(64 * NW, VSUM ? 4 : ((NW == 4 && NSUB == 2) ? 3 : 2
 #pragma unroll
       for (int t = 0; t < NSUB; ++t) {
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + k_base[ks] + t * 32 * 128);
-        if (ks == 0) s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0], PRE ? negm : f32x16{}, 0, 0, 0);
-        else         s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t], 0, 0, 0);
+        if (ks == 0) {
+          if constexpr (PRE && VSUM) s[t] = mfma_from(kf, qf[0], negm);
+          else s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0], PRE ? negm : f32x16{}, 0, 0, 0);
+        } else {
+          s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t], 0, 0, 0);
+        }
       }
     }
 
@@ -247,7 +270,9 @@ __global__ __launch_bounds__(64 * NW, VSUM ? 4 : ((NW == 4 && NSUB == 2) ? 3 : 2
     for (int t = 0; t < NSUB; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
-    mx = pair_max(mx);
+    // (the vote below runs over all 64 lanes, so it needs no exchange with the partner half-wave: the engine form combines
+    //  the two halves of a row only inside the rare rescale branch)
+    if constexpr (!(PRE && VSUM)) mx = pair_max(mx);
     // Deferred rescale: the running max is only raised (and O / the row sums rescaled) when some row's max
     // grew by more than RESCALE_LOG2 in the exp2 domain; otherwise P is taken against the old max and is bounded
     // by 2^RESCALE_LOG2 (bf16 keeps its relative precision, the accumulators are fp32).  Wave-uniform branch.
@@ -255,6 +280,7 @@ __global__ __launch_bounds__(64 * NW, VSUM ? 4 : ((NW == 4 && NSUB == 2) ? 3 : 2
       // s holds score - m_run (exp2 domain).  The first tile always sets the running max (m_run starts at 0, so a row
       // whose scores are all far below zero would otherwise underflow every P).
       if (kb == 0 || !__all(mx <= RESCALE_LOG2)) {
+        if constexpr (VSUM) mx = pair_max(mx);
         const float delta = kb == 0 ? mx : fmaxf(mx, 0.f);     // m_new - m_run
         if (kb != 0) {
           const float alpha = __builtin_amdgcn_exp2f(-delta);
