@@ -18,17 +18,17 @@
 //   softmax         exp2 domain, raw v_exp_f32; generic form: scale folded into one v_fma; engine form (PRE): the scale
 //                   lives in the packed to_q weights and -running_max is the C operand of the first MFMA.  The
 //                   rescale of O is DEFERRED until some row's max grew by > 2^6.  Denominators: a V^T tile whose
-//                   row 0 is all ones (matrix pipe), or -- engine form (VSUM) -- v_dot2c_f32_bf16 on the packed P.
+//                   row 0 is all ones (matrix pipe), or -- engine form (VSUM) -- f32 adds of the exponentials on the vector pipe.
 // KV tiles hold NSUB x 32 keys: 64 by default.  The 128-key variant halves the per-tile fixed costs
 // (barrier, max reduction tree, rescale test, loader address math) but loses a wave per SIMD and
 // measured slower (profiles/r01_probe_attention_kv128.log); it is kept behind MVD_ATTN_KV128=1.  K/V tiles are double
 // buffered in LDS; tile t+1 is fetched under the MFMAs of tile t: by LDS-DMA in the engine's form (DMA), through
 // registers (global_load before the MFMAs, ds_write after them) in the others.
 // The engine form is bound by the vector-issue port (per 64-key tile and wave: 32 v_exp_f32 at 8 issue cycles, 16 converts,
-// 16 dot products, 18 max, 16 MFMAs at 8 -- against 512 matrix cycles), so everything else was taken off that port: the
+// 32 adds for the denominators, 18 max, 16 MFMAs at 8 -- against 512 matrix cycles), so everything else was taken off that port: the
 // score tiles start from the live -max tile without a copy (mfma_from), the DMA destinations are scalar, and the two halves
 // of a row exchange their maxima only inside the rare rescale branch (113 -> 92 non-MFMA vector instructions per tile, -2.4 %).
-// The engine's kernel is attn_kernel<4, 2, PRE, DMA, VSUM>: 4 waves x 32 queries, 123 VGPRs, four workgroups per CU,
+// The engine's kernel is attn_kernel<4, 2, PRE, DMA, VSUM>: 4 waves x 32 queries, 121 VGPRs, four workgroups per CU,
 // workgroups dealt to the XCDs so that all query blocks of a (batch, head) pair share one L2 (attn_block).
 #include <stdlib.h>
 #include "kernels.h"
@@ -94,7 +94,7 @@ MVD_DEVINL void attn_block(const MvdAttnArgs& a, int& qb, int& head, int& bz) {
 
 // DMA: K/V tiles go global -> LDS by buffer-addressed LDS-DMA (no VGPR round trip, no ds_write, 16 registers fewer; the XOR
 // swizzles move to the source side; keys >= nk lie beyond num_records and arrive as zeros) instead of load + ds_write.
-// VSUM (with DMA): the softmax denominators are summed with v_dot2c_f32_bf16 on the packed P instead of the "ones" V^T tile --
+// VSUM (with DMA): the softmax denominators are summed with vector adds instead of the "ones" V^T tile --
 // 16 accumulator registers and 2 of 20 MFMAs per tile less, which brings the kernel under 128 registers: FOUR waves per SIMD.
 template <int NW, int NSUB, bool PRE, bool DMA = false, bool VSUM = false>
 __global__ __launch_bounds__(64 * NW, VSUM ? 4 : ((NW == 4 && NSUB == 2) ? 3 : 2)) void attn_kernel(const MvdAttnArgs a) {
@@ -206,6 +206,7 @@ __global__ __launch_bounds__(64 * NW, VSUM ? 4 : ((NW == 4 && NSUB == 2) ? 3 : 2
   f32x16 o0 = {}, o1 = {};       // O^T tiles: d 0..31 and 32..63 (rows) x query (lane)
   f32x16 ol = {};                // "ones" tile: row 0 (reg 0 of lanes 0..31) = running softmax denominators
   float lsum = 0.f;              // VSUM: this lane's share (its half of the keys) of the denominator of query lq
+  float lsum2 = 0.f;
   bf16x8 ones_frag;
 #pragma unroll
   for (int j = 0; j < 8; ++j) ones_frag[j] = (lq == 0) ? (__bf16)1.0f : (__bf16)0.0f;
@@ -288,6 +289,7 @@ __global__ __launch_bounds__(64 * NW, VSUM ? 4 : ((NW == 4 && NSUB == 2) ? 3 : 2
           for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
           ol[0] *= alpha;
           lsum *= alpha;
+          lsum2 *= alpha;
         }
         m_run += delta;
 #pragma unroll
@@ -338,15 +340,16 @@ __global__ __launch_bounds__(64 * NW, VSUM ? 4 : ((NW == 4 && NSUB == 2) ? 3 : 2
         if (dt == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, o0, 0, 0, 0);
         else         o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, o1, 0, 0, 0);
       }
-      // row sums on the matrix pipe (the softmax VALU stream is the bottleneck at head_dim 64): a V^T tile whose
-      // row 0 is all ones accumulates sum_k P[k][q] -- of the SAME bf16-rounded P the numerator uses -- into ol[0]
+      // row sums: engine form (VSUM) -- plain f32 adds of the exponentials on two chains (v_dot2c_f32_bf16 on the packed P
+      // was measured 0.8 % slower: it prices at ~10 issue cycles against 4 for an add; written as asm so hipcc cannot
+      // SLP-pack them into the slower v_pk_add_f32); otherwise on the matrix pipe: a V^T tile whose row 0 is all ones
+      // accumulates sum_k P[k][q] of the bf16-rounded P into ol[0]
       if constexpr (VSUM) {
-        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-        const bf16x2_t ones2 = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
-        const u32x4 pw = __builtin_bit_cast(u32x4, pb);
-        const unsigned w4[4] = {pw.x, pw.y, pw.z, pw.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) lsum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w4[e]), ones2, lsum, false);
+        for (int j = 0; j < 8; j += 2) {
+          asm("v_add_f32 %0, %0, %1" : "+v"(lsum) : "v"(s[st >> 1][8 * (st & 1) + j]));
+          asm("v_add_f32 %0, %0, %1" : "+v"(lsum2) : "v"(s[st >> 1][8 * (st & 1) + j + 1]));
+        }
       } else {
         ol = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones_frag, pb, ol, 0, 0, 0);
       }
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(64 * NW, VSUM ? 4 : ((NW == 4 && NSUB == 2) ? 3 : 2
   }
 
   // ---- epilogue: O[q][d] = O^T / l ; lane holds d = 32*dt + (r&3) + 8*(r>>2) + 4*lh
-  const float inv = 1.0f / pair_sum(VSUM ? lsum : ol[0]);   // lanes 32..63 hold row 4 of the ones tile (= 0) in ol[0]
+  const float inv = 1.0f / pair_sum(VSUM ? lsum + lsum2 : ol[0]);   // lanes 32..63 hold row 4 of the ones tile (= 0) in ol[0]
   if (qrow < nq) {
     bf16_t* orow = op + (size_t)qrow * P.ldo;
 #pragma unroll
