@@ -18,17 +18,18 @@
 //   softmax         exp2 domain, raw v_exp_f32; generic form: scale folded into one v_fma; engine form (PRE): the scale
 //                   lives in the packed to_q weights and -running_max is the C operand of the first MFMA.  The
 //                   rescale of O is DEFERRED until some row's max grew by > 2^6.  Denominators: a V^T tile whose
-//                   row 0 is all ones (matrix pipe), or -- engine form (VSUM) -- f32 adds of the exponentials on the vector pipe.
+//                   row 0 is all ones (matrix pipe), or -- engine form (VSUM) -- one 16x16x32 MFMA per P fragment against a 0/1 selector (4 registers).
 // KV tiles hold NSUB x 32 keys: 64 by default.  The 128-key variant halves the per-tile fixed costs
 // (barrier, max reduction tree, rescale test, loader address math) but loses a wave per SIMD and
 // measured slower (profiles/r01_probe_attention_kv128.log); it is kept behind MVD_ATTN_KV128=1.  K/V tiles are double
 // buffered in LDS; tile t+1 is fetched under the MFMAs of tile t: by LDS-DMA in the engine's form (DMA), through
 // registers (global_load before the MFMAs, ds_write after them) in the others.
 // The engine form is bound by the vector-issue port (per 64-key tile and wave: 32 v_exp_f32 at 8 issue cycles, 16 converts,
-// 32 adds for the denominators, 18 max, 16 MFMAs at 8 -- against 512 matrix cycles), so everything else was taken off that port: the
-// score tiles start from the live -max tile without a copy (mfma_from), the DMA destinations are scalar, and the two halves
-// of a row exchange their maxima only inside the rare rescale branch (113 -> 92 non-MFMA vector instructions per tile, -2.4 %).
-// The engine's kernel is attn_kernel<4, 2, PRE, DMA, VSUM>: 4 waves x 32 queries, 121 VGPRs, four workgroups per CU,
+// 18 max, 20 MFMAs at 8 -- against 576 matrix cycles), so everything else was taken off that port: the score tiles start from
+// the live -max tile without a copy (mfma_from), the DMA destinations are scalar, the two halves of a row exchange their
+// maxima only inside the rare rescale branch, and the denominators are summed by the matrix pipe (113 -> 76 non-MFMA vector
+// instructions per tile; 17.3 -> 16.0 ms per cfg4 step).
+// The engine's kernel is attn_kernel<4, 2, PRE, DMA, VSUM>: 4 waves x 32 queries, 128 VGPRs, four workgroups per CU,
 // workgroups dealt to the XCDs so that all query blocks of a (batch, head) pair share one L2 (attn_block).
 #include <stdlib.h>
 #include "kernels.h"
@@ -94,8 +95,8 @@ MVD_DEVINL void attn_block(const MvdAttnArgs& a, int& qb, int& head, int& bz) {
 
 // DMA: K/V tiles go global -> LDS by buffer-addressed LDS-DMA (no VGPR round trip, no ds_write, 16 registers fewer; the XOR
 // swizzles move to the source side; keys >= nk lie beyond num_records and arrive as zeros) instead of load + ds_write.
-// VSUM (with DMA): the softmax denominators are summed with vector adds instead of the "ones" V^T tile --
-// 16 accumulator registers and 2 of 20 MFMAs per tile less, which brings the kernel under 128 registers: FOUR waves per SIMD.
+// VSUM (with DMA): the softmax denominators are summed by 16x16x32 selector MFMAs (4 registers) instead of the "ones" V^T tile --
+// 12 accumulator registers less, which keeps the kernel at 128 registers: FOUR waves per SIMD.
 template <int NW, int NSUB, bool PRE, bool DMA = false, bool VSUM = false>
 __global__ __launch_bounds__(64 * NW, VSUM ? 4 : ((NW == 4 && NSUB == 2) ? 3 : 2)) void attn_kernel(const MvdAttnArgs a) {
   constexpr int NT = 64 * NW;
@@ -205,8 +206,25 @@ __global__ __launch_bounds__(64 * NW, VSUM ? 4 : ((NW == 4 && NSUB == 2) ? 3 : 2
 
   f32x16 o0 = {}, o1 = {};       // O^T tiles: d 0..31 and 32..63 (rows) x query (lane)
   f32x16 ol = {};                // "ones" tile: row 0 (reg 0 of lanes 0..31) = running softmax denominators
+#ifdef MVD_ATTN_SUM_ADDS
   float lsum = 0.f;              // VSUM: this lane's share (its half of the keys) of the denominator of query lq
   float lsum2 = 0.f;
+#endif
+  // VSUM: the softmax denominators on the matrix pipe at FOUR registers: one 16x16x32 MFMA per packed P fragment whose A
+  // operand is a 0/1 selector.  As the B operand of that shape, lane l supplies k-group l >> 4 of column l & 15, so the
+  // fragments of query n (lanes n, n + 32: its two key halves) are k-groups 0 and 2 of column n and those of query n + 16
+  // (lanes n + 16, n + 48) are k-groups 1 and 3: selector row 0 = ones over k-groups {0, 2}, row 1 = ones over {1, 3}, other
+  // rows zero.  Lanes 0..15 then hold the COMPLETE denominators (both key halves) of query n in lacc[0] and of query
+  // n + 16 in lacc[1] -- of the bf16-rounded P the numerators use.  4 MFMAs (32 issue cycles, 64 matrix cycles) per tile
+  // instead of 32 v_add_f32 (128 issue cycles) on the vector-issue port this kernel is bound by.
+  f32x4 lacc = {0.f, 0.f, 0.f, 0.f};
+  bf16x8 sel;
+  {
+    const int sm = lane & 15, sg = (lane >> 4) & 1;
+    const __bf16 one = (sm == sg && sm < 2) ? (__bf16)1.0f : (__bf16)0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sel[j] = one;
+  }
   bf16x8 ones_frag;
 #pragma unroll
   for (int j = 0; j < 8; ++j) ones_frag[j] = (lq == 0) ? (__bf16)1.0f : (__bf16)0.0f;
@@ -288,8 +306,15 @@ __global__ __launch_bounds__(64 * NW, VSUM ? 4 : ((NW == 4 && NSUB == 2) ? 3 : 2
 #pragma unroll
           for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
           ol[0] *= alpha;
+#ifdef MVD_ATTN_SUM_ADDS
           lsum *= alpha;
           lsum2 *= alpha;
+#else
+          if constexpr (VSUM) {          // holder lane n: query n's factor is its own, query n + 16's is lane n + 16's
+            lacc[0] *= alpha;
+            lacc[1] *= __shfl(alpha, (lane + 16) & 63, 64);
+          }
+#endif
         }
         m_run += delta;
 #pragma unroll
@@ -340,16 +365,19 @@ __global__ __launch_bounds__(64 * NW, VSUM ? 4 : ((NW == 4 && NSUB == 2) ? 3 : 2
         if (dt == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, o0, 0, 0, 0);
         else         o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, o1, 0, 0, 0);
       }
-      // row sums: engine form (VSUM) -- plain f32 adds of the exponentials on two chains (v_dot2c_f32_bf16 on the packed P
-      // was measured 0.8 % slower: it prices at ~10 issue cycles against 4 for an add; written as asm so hipcc cannot
-      // SLP-pack them into the slower v_pk_add_f32); otherwise on the matrix pipe: a V^T tile whose row 0 is all ones
-      // accumulates sum_k P[k][q] of the bf16-rounded P into ol[0]
+      // row sums: engine form (VSUM) -- the selector MFMA (see lacc above; measured against the alternatives on the vector
+      // pipe: 16 v_dot2c_f32_bf16 on the packed P 16.44 ms/step, 32 plain v_add_f32 on two chains 16.30 (MVD_ATTN_SUM_ADDS
+      // builds), this 16.00); otherwise a V^T tile whose row 0 is all ones accumulates sum_k P[k][q] into ol[0] (16 registers)
       if constexpr (VSUM) {
+#ifdef MVD_ATTN_SUM_ADDS
 #pragma unroll
         for (int j = 0; j < 8; j += 2) {
           asm("v_add_f32 %0, %0, %1" : "+v"(lsum) : "v"(s[st >> 1][8 * (st & 1) + j]));
           asm("v_add_f32 %0, %0, %1" : "+v"(lsum2) : "v"(s[st >> 1][8 * (st & 1) + j + 1]));
         }
+#else
+        lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sel, pb, lacc, 0, 0, 0);
+#endif
       } else {
         ol = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones_frag, pb, ol, 0, 0, 0);
       }
@@ -360,7 +388,17 @@ __global__ __launch_bounds__(64 * NW, VSUM ? 4 : ((NW == 4 && NSUB == 2) ? 3 : 2
   }
 
   // ---- epilogue: O[q][d] = O^T / l ; lane holds d = 32*dt + (r&3) + 8*(r>>2) + 4*lh
+#ifdef MVD_ATTN_SUM_ADDS
   const float inv = 1.0f / pair_sum(VSUM ? lsum + lsum2 : ol[0]);   // lanes 32..63 hold row 4 of the ones tile (= 0) in ol[0]
+#else
+  float inv;
+  if constexpr (VSUM) {
+    const float d0 = __shfl(lacc[0], lq & 15, 64), d1 = __shfl(lacc[1], lq & 15, 64);
+    inv = 1.0f / (lq < 16 ? d0 : d1);
+  } else {
+    inv = 1.0f / pair_sum(ol[0]);        // lanes 32..63 hold row 4 of the ones tile (= 0) in ol[0]
+  }
+#endif
   if (qrow < nq) {
     bf16_t* orow = op + (size_t)qrow * P.ldo;
 #pragma unroll
