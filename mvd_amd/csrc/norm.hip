@@ -529,11 +529,16 @@ int mvd_launch_groupnorm(const bf16_t* x0, const bf16_t* x1, int c0, int c1, int
   if (vec > 1024) { mvd_set_error("groupnorm: C=%d too wide", C); return -1; }
   const int R = vec >= 256 ? 1 : 256 / vec;
   const int threads = ((vec * R + 63) / 64) * 64;
-  // enough workgroups to cover the chip even at batch 1: >= ~512 blocks when the map is large enough,
-  // at least 8 rows per chunk
+  // enough workgroups for the statistics pass at small batch, at least 8 rows per chunk
   static const int rows_target = MVD_ENV_INT("MVD_GN_ROWS", 128);
   int nchunk = hw / rows_target;
-  if ((long)nchunk * batch < 512) nchunk = (512 + batch - 1) / batch;
+  // (every apply block re-merges the nchunk partials of its image, so more chunks than the statistics pass needs to be
+  //  parallel cost more there than they win here: at batch 1, 64 x 64 x 320, a floor of 512 blocks -- 256 chunks -- made the
+  //  apply kernel 22.7 us (rocprof); 64 blocks: GroupNorm 1.05 -> 0.88 ms per batch-1 forward, 128: 0.90)
+#ifndef MVD_GN_MINBLOCKS
+#define MVD_GN_MINBLOCKS 64
+#endif
+  if ((long)nchunk * batch < MVD_GN_MINBLOCKS) nchunk = (MVD_GN_MINBLOCKS + batch - 1) / batch;
   if (nchunk > hw / 8) nchunk = hw / 8;
   nchunk = nchunk < 1 ? 1 : (nchunk > MVD_GN_MAXCHUNK ? MVD_GN_MAXCHUNK : nchunk);
   const int rpc = (hw + nchunk - 1) / nchunk;
