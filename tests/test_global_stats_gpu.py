@@ -43,13 +43,17 @@ def test_sharded_forward_with_global_statistics_equals_unsharded_batch():
         glob = [_shard_forward(m, inp, r, t, merged=merged) for m, r in zip(ranks, shards)]
     torch.cuda.synchronize()
     glob, local = torch.cat(glob), torch.cat(local)
-    e_oracle, e_whole, e_local = rel_l2(glob, want), rel_l2(glob, whole.cpu()), rel_l2(local, whole.cpu())
-    print(f"global-stats shards vs oracle(whole batch) {e_oracle:.4f}  vs engine(whole batch) {e_whole:.4f}  "
-          f"local-stats shards vs engine(whole batch) {e_local:.4f}")
+    e_glob, e_loc = rel_l2(glob, want), rel_l2(local, want)
+    e_whole, e_gw = rel_l2(whole, want), rel_l2(glob, whole.cpu())
+    print(f"vs the oracle on the whole batch: global-stats shards {e_glob:.4f}  local-stats shards {e_loc:.4f}  "
+          f"engine on the whole batch {e_whole:.4f};  global-stats shards vs engine on the whole batch {e_gw:.4f}")
     assert torch.isfinite(glob).all()
-    assert e_oracle < 3e-2            # the bf16 engine-vs-oracle tolerance of the other end-to-end tests
-    assert e_whole < 1e-2             # same arithmetic as the whole batch up to bf16 rounding / tile-shape differences
-    assert e_local > 2 * e_whole      # the test bites: per-shard statistics give a measurably different result
+    # the fp32 oracle is the noise-free yardstick (two bf16 engine runs at different batch sizes differ by about as much as
+    # either differs from it): with the exchange the shards are as close to the unsharded reference as the unsharded engine
+    # run is -- the stated end-to-end tolerance -- and per-shard statistics are measurably further away
+    assert e_glob < 2e-2 and e_glob < 1.25 * e_whole + 2e-3
+    assert e_loc > 1.2 * e_glob       # the test bites: replica-local statistics give a different (the DDP) result
+    assert e_gw < 2e-2
 
 
 def test_one_rank_global_mode_matches_the_fused_reference_pass():
