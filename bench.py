@@ -3,7 +3,9 @@
 SD-2.1 UNet + MVD camera/cross-view adapter hot path on MI355X.
 
     python bench.py --gpus 1 --steps K --warmup W            (single GPU)
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W            (starts N ranks itself: the parent never touches a GPU,
+                                                              it runs torch.distributed.run as a child and relays rank 0's line)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU, launcher form)
 
 A "step" is one ``MultiViewUNet.forward`` over one batch of synthetic (source -> target) pairs that
 is already resident in HBM.  The default workload is BASELINE.json configs[3] per GPU (8 objects x 4
@@ -31,6 +33,45 @@ import torch  # noqa: E402
 
 # algorithmic FLOPs per (source -> target) pair per forward (2*MAC over convs, linears, QK^T/PV): SURVEY.md 8d
 F_BASE, F_ADAPTER_MAIN, F_ENCODER = 804.26e9, 1151.59e9, 804.26e9
+
+
+def unet_flops(H: int, W: int, L: int = 77, adapter: bool = False, xd: int = 1024) -> float:
+    """SURVEY.md 8d's count for any latent size: 2*MAC over convs, linears and QK^T / PV of the SD-2.1 topology (norms,
+    activations, softmax excluded); ``adapter`` adds the cross-view branch of all 16 transformer sites (q_ref, attention
+    over the reference tokens, to_out_ref, K_ref / V_ref projections).  64 x 64: 804.26 / 1151.59 GFLOP (the SURVEY's
+    figures); 96 x 96 (768^2 images): 2149.11 / 3619.63 GFLOP."""
+    ch, n, Lb = [320, 640, 1280, 1280], 4, 2
+    fl = 2 * H * W * 320 * 36 + 2 * (320 * 1280 + 1280 * 1280) + 2 * H * W * 4 * 9 * 320
+
+    def resnet(ci, co, hw):
+        return 2 * hw * co * 9 * ci + 2 * hw * co * 9 * co + 2 * 1280 * co + (2 * hw * co * ci if ci != co else 0)
+
+    def tr(C, hw):
+        f = 40 * hw * C * C + 4 * hw * hw * C + 4 * hw * L * C + 4 * L * xd * C
+        return f + (16 * hw * C * C + 8 * hw * hw * C if adapter else 0)
+
+    h, w, prev, skips = H, W, 320, [320]
+    for i in range(n):
+        co = ch[i]
+        for j in range(Lb):
+            fl += resnet(prev if j == 0 else co, co, h * w) + (tr(co, h * w) if i < n - 1 else 0)
+            skips.append(co)
+        prev = co
+        if i < n - 1:
+            h, w = h // 2, w // 2
+            fl += 2 * h * w * co * 9 * co
+            skips.append(co)
+    fl += 2 * resnet(1280, 1280, h * w) + tr(1280, h * w)
+    prev_out = 1280
+    for i in range(n):
+        co = ch[n - 1 - i]
+        for j in range(Lb + 1):
+            fl += resnet((prev_out if j == 0 else co) + skips.pop(), co, h * w) + (tr(co, h * w) if i > 0 else 0)
+        prev_out = co
+        if i < n - 1:
+            h, w = 2 * h, 2 * w
+            fl += 2 * h * w * co * 9 * co
+    return float(fl)
 PEAK_BF16_MFMA = 2.5e15          # dense, /opt/skills/guides/MI355X_MICROARCH.md:43
 PEAK_HBM = 8.0e12
 
@@ -57,7 +98,7 @@ def fill_synthetic_weights(model, seed: int = 0):
     model.mark_weights_changed()
 
 
-def make_batch(pairs: int, rank: int, device):
+def make_batch(pairs: int, rank: int, device, lat_hw: int = 64):
     """8 objects x 4 target views per 32 pairs.  As pipeline.py:111-116 does, each object's source IMAGE (and prompt) is
     repeated per view, and ``latent_dist.sample()`` then draws a separate latent per ROW: the text rows repeat 4x, the
     32 source latents are distinct (a shared per-object mean plus per-row posterior noise).  The engine makes no use of
@@ -66,10 +107,10 @@ def make_batch(pairs: int, rank: int, device):
     g = torch.Generator().manual_seed(1000 + rank)
     objs = max(1, pairs // 4)
     views = pairs // objs
-    sample = torch.randn(pairs, 4, 64, 64, generator=g)
+    sample = torch.randn(pairs, 4, lat_hw, lat_hw, generator=g)
     text = torch.randn(objs, 77, 1024, generator=g).repeat_interleave(views, 0)
-    mean = torch.randn(objs, 4, 64, 64, generator=g).repeat_interleave(views, 0)              # pipeline.py:111-113
-    lat = 0.18215 * (mean + 0.1 * torch.randn(pairs, 4, 64, 64, generator=g))                  # pipeline.py:115-116
+    mean = torch.randn(objs, 4, lat_hw, lat_hw, generator=g).repeat_interleave(views, 0)      # pipeline.py:111-113
+    lat = 0.18215 * (mean + 0.1 * torch.randn(pairs, 4, lat_hw, lat_hw, generator=g))          # pipeline.py:115-116
     src = torch.stack([look_at(0.0)] * pairs)
     tgt = torch.stack([look_at([45.0, 90.0, 180.0, 270.0][i % 4]) for i in range(pairs)])
     t = torch.full((pairs,), 500.0)
@@ -163,6 +204,32 @@ def output_check(model, batch, kw, step):
     return res
 
 
+def launch_dry_run(args, D):
+    """The N > 1 control flow of main() with the GPU work left out (CPU test of the self-launching entry): gloo process
+    group from the launcher's environment, a weight-arena broadcast through the product's own helper, the barriers and the
+    max-over-ranks reduction, rank 0's line.  The numbers mean nothing."""
+    rank, world, _ = D.init_from_env("gloo", set_device=False)
+    g = torch.Generator().manual_seed(7)
+    ref = {"a.w": torch.randn(300, 64, generator=g).to(torch.bfloat16), "a.b": torch.randn(300, generator=g)}
+    mine = ref if rank == 0 else {k: torch.zeros_like(v) for k, v in ref.items()}
+    arenas, views = D.pack_into_arenas(mine)
+    bc = D.broadcast_arenas(arenas.values(), 0)
+    ok = all(torch.equal(views[k], ref[k]) for k in ref)
+    D.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    D.barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, "cpu")
+    if rank == 0:
+        print(json.dumps({"metric": "launch dry run (no GPU work)", "value": 0.0, "unit": "forward-passes/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3, 3),
+                          "weight_broadcast": {"bytes": bc["bytes"], "seconds": round(bc["seconds"], 4), "buckets": bc["buckets"]},
+                          "broadcast_ok": bool(ok), "dry_run": True}), flush=True)
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -178,9 +245,29 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the determinism / cross-path output screens")
     ap.add_argument("--shapes-out", default="", help="write the per-shape kernel table of the profiled steps to this file")
+    ap.add_argument("--latent", type=int, default=64, help="latent height = width (64 = 512x512 images, 96 = the reference's 768x768 default, infer.py:187)")
+    ap.add_argument("--launch-dry-run", action="store_true",
+                    help="control flow only (no GPU, gloo): process group, a small arena broadcast, barriers, max over ranks, rank 0's line")
     args = ap.parse_args()
 
+    # ---- self-launch: `python bench.py --gpus N` without a launcher starts the N ranks itself.  Nothing in this process has
+    # touched a GPU at this point (importing torch does not), and nothing will: the ranks are fresh children of
+    # torch.distributed.run, whose stdout (rank 0's single JSON line) and exit code are passed through.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.run(cmd, env=env).returncode)
+
     from mvd_amd import distributed as D
+    if args.launch_dry_run:
+        return launch_dry_run(args, D)
     # MVD_BENCH_REHEARSAL=1: every rank on cuda:0 with the gloo backend -- a one-GPU rehearsal of the N > 1 control flow
     # (weight broadcast, barriers, max over ranks); the numbers of such a run mean nothing
     rehearsal = os.environ.get("MVD_BENCH_REHEARSAL") == "1"
@@ -224,7 +311,7 @@ def main():
     model._dirty = False
     torch.cuda.empty_cache()
 
-    batch = make_batch(pairs, rank, dev)
+    batch = make_batch(pairs, rank, dev, args.latent)
     kw = {}
     if use_cam:
         kw.update(source_camera=batch["src"], target_camera=batch["tgt"])
@@ -255,7 +342,10 @@ def main():
     gpu_ms = e0.elapsed_time(e1)
 
     forward_kind = "base" if not use_img else ("cached" if args.cached else "cold")
-    flops_pair = F_BASE if not use_img else (F_ADAPTER_MAIN if args.cached else F_ADAPTER_MAIN + F_ENCODER)
+    f_base, f_main = unet_flops(args.latent, args.latent), unet_flops(args.latent, args.latent, adapter=True)
+    if args.latent == 64:
+        assert abs(f_base - F_BASE) < 1e7 and abs(f_main - F_ADAPTER_MAIN) < 1e7, (f_base, f_main)   # SURVEY 8d's figures
+    flops_pair = f_base if not use_img else (f_main if args.cached else f_main + f_base)
     total_pairs = pairs * world
     value = total_pairs * args.steps / elapsed
 
@@ -287,7 +377,7 @@ def main():
             try:
                 pmc = json.load(open(os.path.join(ROOT, traffic_file)))
                 # only a summary taken on THIS kernel source state and THIS workload is quoted (else null)
-                if (pmc.get("_meta", {}).get("kernel_src_sha") == kernel_source_sha() and args.workload == "cfg4"
+                if (pmc.get("_meta", {}).get("kernel_src_sha") == kernel_source_sha() and args.workload == "cfg4" and args.latent == 64
                         and not args.cached and dom in pmc):
                     traffic = round(pmc[dom]["hbm_bytes_per_launch"])
             except (OSError, ValueError):
@@ -317,7 +407,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "pairs_per_gpu": pairs, "global_pairs": total_pairs,
-                       "latent": "64x64x4", "text_tokens": 77, "forward": forward_kind, "hip_graph": bool(args.graph), "q2_statistics": "global" if args.global_ref_stats else "replica-local",
+                       "latent": f"{args.latent}x{args.latent}x4", "image": f"{8 * args.latent}x{8 * args.latent}", "text_tokens": 77, "forward": forward_kind, "hip_graph": bool(args.graph), "q2_statistics": "global" if args.global_ref_stats else "replica-local",
                        "gflop_per_pair": round(flops_pair / 1e9, 2), "parallelism": f"dp{world} (pairs sharded by object)",
                        "weights": "synthetic seeded, SD2.1 shapes (865.9M UNet x2 + 99.2M adapter + 19.1M camera)"},
             "roofline": roofline, "cpu_baseline": cpu, "output_check": check, "kernel_src_sha": kernel_source_sha(),

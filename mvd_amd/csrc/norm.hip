@@ -107,7 +107,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
     // pass 1 the global mean, pass 2 M2 = sum M2_c + n_c (mean_c - mean)^2
     const int g = threadIdx.x >> 3, part = threadIdx.x & 7;
     const float* wg = ws + ((size_t)b * nchunk_stats * groups + (g < groups ? g : 0)) * 2;
-    auto rows_of = [&](int ck) { return min(hw, (ck + 1) * rows_per_chunk_stats) - ck * rows_per_chunk_stats; };
+    // (clamped: a chunk that starts at or beyond hw holds no rows -- the launcher never makes one, see nchunk below)
+    auto rows_of = [&](int ck) { return max(0, min(hw, (ck + 1) * rows_per_chunk_stats) - ck * rows_per_chunk_stats); };
     float s = 0.f;
     if (g < groups)
       for (int ck = part; ck < nchunk_stats; ck += 8) s += wg[(size_t)ck * groups * 2] * (float)rows_of(ck);
@@ -542,7 +543,7 @@ int mvd_launch_groupnorm(const bf16_t* x0, const bf16_t* x1, int c0, int c1, int
   if (nchunk > hw / 8) nchunk = hw / 8;
   nchunk = nchunk < 1 ? 1 : (nchunk > MVD_GN_MAXCHUNK ? MVD_GN_MAXCHUNK : nchunk);
   const int rpc = (hw + nchunk - 1) / nchunk;
-  nchunk = (hw + rpc - 1) / rpc;
+  nchunk = (hw + rpc - 1) / rpc;      // no empty trailing chunk (hw = 1296, 64 chunks: rpc 21 -> 62 chunks)
   const size_t sh1 = (size_t)R * C * 2 * sizeof(float);
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, batch), dim3(threads), sh1, s, x0, x1, c0, c1, hw, groups, rpc, R, ws);
   if (int r = check_launch("gn_stats")) return r;

@@ -189,9 +189,23 @@ def merge_stat_parts(parts: Sequence[torch.Tensor]) -> torch.Tensor:
         n = tot
     # the last step in fp32, as refnorm_kernel does it (var = M2 / (n - 1); k = 0.5 / max(sqrt(var), 1e-6)): with ONE part
     # the result is then bit-identical to the fused reference pass
+    # (n = batch x channels per pixel, >= 64 for every feature map of the engine (channels % 64 == 0), so n - 1 > 0; a
+    #  single-sample pixel would give NaN exactly like torch.std(unbiased) in attention.py:99 -- not checked here because
+    #  reading n back would put a host sync into every cold forward)
     mean, m2, n = mean.float(), m2.float(), n.float()
     k = 0.5 / (m2 / (n - 1.0)).sqrt().clamp_min(1e-6)
     return torch.stack([mean, k], dim=1).contiguous()
+
+
+def any_rank(flag: bool, group=None, device=None) -> bool:
+    """True on every rank of ``group`` iff ``flag`` is true on at least one of them (one 8-byte all-reduce; no process
+    group or world size 1: ``flag`` itself).  Used to make "re-run the reference pass?" a collective decision."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return bool(flag)
+    on_host = dist.get_backend(group) == "gloo"
+    t = torch.tensor([1 if flag else 0], dtype=torch.int64, device="cpu" if on_host or device is None else device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return bool(t.item())
 
 
 def max_over_ranks(value: float, device) -> float:

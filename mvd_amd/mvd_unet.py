@@ -303,8 +303,14 @@ class MultiViewUNet(nn.Module):
             key = (source_image_latents.data_ptr(), source_image_latents._version, tuple(source_image_latents.shape),
                    encoder_hidden_states.data_ptr(), encoder_hidden_states._version, tuple(encoder_hidden_states.shape), B)
             glob = self.reference_stats_group is not None
-            if (self.cache_reference and self._ref_key == key
-                    and eng.reference_cache_valid(B, x.shape[2], x.shape[3], text.shape[1], bs)):
+            hit = (self.cache_reference and self._ref_key == key
+                   and eng.reference_cache_valid(B, x.shape[2], x.shape[3], text.shape[1], bs))
+            if glob and self.cache_reference:
+                # the recompute path below contains a collective: the decision must be the same on every rank of the group
+                # (a re-bound workspace or a fresh tensor on ONE rank would otherwise leave the others out of the all-gather)
+                from .distributed import any_rank
+                hit = not any_rank(not hit, None if self.reference_stats_group is True else self.reference_stats_group, dev)
+            if hit:
                 img = dict(reuse_ref=True, keep_features=glob)
             else:
                 img = dict(source_latents=self._f32(source_image_latents, dev), encoder_text=enc_text.contiguous())

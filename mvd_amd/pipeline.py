@@ -69,7 +69,9 @@ class MVDDenoiser:
             if guidance_scale > 1.0:                                            # pipeline.py:156-158
                 out = ops.cfg_combine(out.float().contiguous(), guidance_scale)
             nz = None if noise_per_step is None else noise_per_step[i]
-            latents = self.scheduler.step(out.float().contiguous(), t, latents, generator=generator, noise=nz).prev_sample
+            # pipeline.py:161 calls scheduler.step(noise_pred, t, latents) WITHOUT the generator: the ancestral noise comes from
+            # torch's global RNG (of the latents' device), the caller's generator only seeds the initial latents
+            latents = self.scheduler.step(out.float().contiguous(), t, latents, noise=nz).prev_sample
             if callback is not None and i % callback_steps == 0:                # pipeline.py:165-166
                 callback(i, t, latents)
         return latents
@@ -210,10 +212,13 @@ def _optional_components(path, dtype):
         return vae, text_encoder, tokenizer
     try:
         from .vae import AutoencoderKLHIP
-        if os.path.exists(os.path.join(str(path), "vae", "diffusion_pytorch_model.safetensors")):
-            vae = AutoencoderKLHIP.from_snapshot(os.path.join(str(path), "vae"))
     except ImportError:
-        vae = None
+        AutoencoderKLHIP = None
+    if AutoencoderKLHIP is not None and os.path.exists(os.path.join(str(path), "vae", "diffusion_pytorch_model.safetensors")):
+        try:
+            vae = AutoencoderKLHIP.from_snapshot(os.path.join(str(path), "vae"))
+        except Exception as e:   # a snapshot that is there but does not load is an error, not "no VAE"
+            raise L.MvdError(f"VAE snapshot under {os.path.join(str(path), 'vae')} failed to load: {type(e).__name__}: {e}") from e
     try:
         from transformers import CLIPTextModel, CLIPTokenizer
         if os.path.isdir(os.path.join(str(path), "text_encoder")) and os.path.isdir(os.path.join(str(path), "tokenizer")):

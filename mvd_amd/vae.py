@@ -215,9 +215,25 @@ class AutoencoderKLHIP(nn.Module):
         m.load_state_dict(load_file(os.path.join(path, "diffusion_pytorch_model.safetensors")))
         return m
 
+    @staticmethod
+    def convert_deprecated_attention_keys(sd):
+        """The published SD-2.1 VAE stores its mid-block attention under the pre-refactor names
+        (``mid_block.attentions.0.{query,key,value,proj_attn}``, 1x1-conv shaped ``(C, C, 1, 1)`` in the oldest files);
+        diffusers renames them on load (``_convert_deprecated_attention_blocks``).  Same mapping here."""
+        ren = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
+        out = {}
+        for k, v in sd.items():
+            parts = k.split(".")
+            if len(parts) >= 3 and "attentions" in parts and parts[-2] in ren:
+                k = ".".join(parts[:-2] + [ren[parts[-2]], parts[-1]])
+            if ".attentions." in k and k.endswith(".weight") and v.dim() == 4 and v.shape[2:] == (1, 1):
+                v = v.reshape(v.shape[0], v.shape[1])
+            out[k] = v
+        return out
+
     def load_state_dict(self, sd, strict: bool = True, **kw):
         self._dirty = True
-        return super().load_state_dict(sd, strict=strict, **kw)
+        return super().load_state_dict(self.convert_deprecated_attention_keys(sd), strict=strict, **kw)
 
     def to(self, *a, **k):
         self._dirty = True

@@ -242,6 +242,18 @@ def test_groupnorm(ops, B, hw, c0, c1, silu):
     close(got, want, what="groupnorm")
 
 
+@pytest.mark.parametrize("B,hw,C", [(1, 1296, 640), (1, 1296, 1920), (1, 784, 1920), (2, 676, 2560), (1, 5184, 320), (1, 9216, 960)])
+def test_groupnorm_two_kernel_ragged_chunks_large_mean(ops, B, hw, C):
+    """Two-kernel form (gn_stats / gn_apply) at pixel counts the chunk size does not divide (72x72, 56x56, 52x52 latents at batch
+    1-2), with |mean| >> std per group: the per-chunk (mean, M2) merge must not see chunks of negative size (round-2 advisor)."""
+    x = (rnd(B, hw, C, seed=11, dtype=torch.float32) + 60.0).to(torch.bfloat16)
+    g = 1 + 0.1 * rnd(C, seed=3, dtype=torch.float32)
+    b = 0.1 * rnd(C, seed=4, dtype=torch.float32)
+    want = F.group_norm(x.double().permute(0, 2, 1), 32, g.double(), b.double(), 1e-5).permute(0, 2, 1)
+    got = ops.groupnorm(x.cuda(), g.cuda(), b.cuda(), silu=False)
+    close(got, want.float(), what=f"groupnorm {B}x{hw}x{C} mean 60")
+
+
 @pytest.mark.parametrize("rows,c", [(100, 320), (7, 640), (33, 1280), (5, 64)])
 def test_layernorm(ops, rows, c):
     x = rnd(rows, c, seed=1, scale=3.0)

@@ -1,0 +1,104 @@
+"""Host-side behaviour added in round 3 (CPU only): the self-launching bench entry, the caller-side contract of the
+denoise loop (scheduler.step gets no generator, pipeline.py:161), the deprecated VAE attention key names."""
+import json
+import os
+import subprocess
+import sys
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_gpus2_starts_two_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher in front: the parent starts torch.distributed.run, two gloo ranks run
+    the control flow (arena broadcast, barriers, max over ranks) and rank 0's single JSON line comes back with n_gpus 2."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--launch-dry-run"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1
+    assert line["weight_broadcast"]["bytes"] > 0 and line["broadcast_ok"] is True
+    assert line["ms_per_step"] >= 20.0        # the max over ranks (rank 1 sleeps 20 ms), not rank 0's own 10 ms
+
+
+def test_bench_flop_counter_reproduces_survey_figures():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert abs(bench.unet_flops(64, 64) - 804.26e9) < 1e7
+    assert abs(bench.unet_flops(64, 64, adapter=True) - 1151.59e9) < 1e7
+    assert bench.unet_flops(96, 96) > 2.25 * bench.unet_flops(64, 64)      # self-attention grows with tokens squared
+
+
+def test_denoise_loop_does_not_hand_the_generator_to_scheduler_step():
+    """/root/reference/src/models/pipeline.py:161 is ``self.scheduler.step(noise_pred, t, latents)``: the caller's generator
+    seeds the initial latents only; the ancestral noise comes from the global RNG."""
+    from mvd_amd.pipeline import MVDDenoiser
+    seen = []
+
+    class Sched:
+        init_noise_sigma = 1.0
+        timesteps = torch.tensor([9, 5, 1])
+
+        def set_timesteps(self, n):
+            pass
+
+        def step(self, model_output, t, sample, **kw):
+            seen.append(kw)
+            return SimpleNamespace(prev_sample=sample - 0.1 * model_output)
+
+    class UNet:
+        def _exec_device(self):
+            return torch.device("cpu")
+
+        def __call__(self, sample, timestep, encoder_hidden_states, **kw):
+            return SimpleNamespace(sample=sample * 0.5)
+
+    g = torch.Generator().manual_seed(3)
+    out = MVDDenoiser(UNet(), Sched())(torch.zeros(2, 7, 16), num_inference_steps=3, guidance_scale=1.0, generator=g,
+                                       height=8, width=8)
+    assert out.shape == (2, 4, 8, 8) and len(seen) == 3
+    assert all("generator" not in kw or kw["generator"] is None for kw in seen)
+    want = torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(3))
+    for _ in range(3):
+        want = want - 0.1 * (want * 0.5)
+    assert torch.allclose(out, want)
+
+
+def test_vae_accepts_deprecated_attention_key_names():
+    """The published SD-2.1 VAE file uses mid_block.attentions.0.{query,key,value,proj_attn} (conv-shaped in the oldest
+    files); diffusers renames them on load and so must the mirror (strict load)."""
+    from mvd_amd.vae import AutoencoderKLHIP, VAEConfig
+    cfg = VAEConfig(block_out_channels=(32, 64), layers_per_block=1, norm_num_groups=8)
+    a, b = AutoencoderKLHIP(cfg), AutoencoderKLHIP(cfg)
+    ren = {"to_q": "query", "to_k": "key", "to_v": "value", "to_out.0": "proj_attn"}
+    old = {}
+    for k, v in a.state_dict().items():
+        for new, dep in ren.items():
+            if f".attentions.0.{new}." in k:
+                k = k.replace(f".{new}.", f".{dep}.")
+                if k.endswith(".weight"):
+                    v = v.reshape(*v.shape, 1, 1)
+        old[k] = v
+    assert any(".query." in k for k in old) and not any(".to_q." in k for k in old)
+    missing, unexpected = b.load_state_dict(old, strict=True)
+    assert not missing and not unexpected
+    for (k1, v1), (k2, v2) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+
+
+def test_vae_snapshot_that_fails_to_load_is_an_error_not_a_missing_vae(tmp_path):
+    from mvd_amd import _lib as L
+    from mvd_amd.pipeline import _optional_components
+    from safetensors.torch import save_file
+    d = tmp_path / "snap" / "vae"
+    d.mkdir(parents=True)
+    (d / "config.json").write_text(json.dumps({"block_out_channels": [32, 64], "layers_per_block": 1, "norm_num_groups": 8}))
+    save_file({"bogus.weight": torch.zeros(3)}, str(d / "diffusion_pytorch_model.safetensors"))
+    with pytest.raises(L.MvdError, match="failed to load"):
+        _optional_components(str(tmp_path / "snap"), torch.float32)
