@@ -196,6 +196,13 @@ int mvd_debug_last_gemm_plan(int* out);
 int mvd_debug_last_attention_plan(int* out);
 /* The split-K factor the engine's schedule picks for a GEMM/conv of this size (1 = none). */
 int mvd_debug_pick_splitk(int m, int n, int k, int geglu);
+/* Small-M kernels (gemm_sm.hip, the batch-1 path): force_cfg = 100 + 10 * tile + ring depth in mvd_op_linear / mvd_op_conv3x3
+ * (tiles 0..6 = 64x64, 128x64, 64x128, 128x128, 64x160, 128x160, 64x320; + 1000: the weight is in the blocked LDS-image
+ * layout of mvd_amd.packing.block_weight).  With splitk > 1 these kernels combine the slices themselves: splitk_ws then
+ * needs splitk*m*n floats + 4096 further 4-byte words (tile arrival counters, zeroed by the call). */
+int mvd_gemm_sm_num_tiles(void);
+/* Measurement hook: log2(waves per attention workgroup) for every later launch of this process; -1 = heuristic. */
+int mvd_debug_set_attention_nw(int nw_log2);
 
 /* ---- denoising-loop helpers either side of the UNet, fp32 latents ------ */
 /* DDPM ancestral step, coefficients from mvd_amd/scheduler.py (diffusers DDPMScheduler.step algebra):

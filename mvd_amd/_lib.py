@@ -96,6 +96,8 @@ _SIGS = {
     "mvd_debug_last_gemm_plan": (C.c_int, [C.POINTER(C.c_int)]),
     "mvd_debug_last_attention_plan": (C.c_int, [C.POINTER(C.c_int)]),
     "mvd_debug_pick_splitk": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mvd_gemm_sm_num_tiles": (C.c_int, []),
+    "mvd_debug_set_attention_nw": (C.c_int, [C.c_int]),
     "mvd_op_ddpm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float,
                                    C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
     "mvd_op_cfg_combine": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -900,6 +900,9 @@ int launch_nw(const MvdAttnArgs& a, int maxq, hipStream_t s) {
 }  // namespace
 
 int mvd_attention_pick_nw(const MvdAttnArgs& a);
+static int g_attn_nw_override = -1;
+// measurement hook (tools/, bench.py --attn-nw): log2 of the waves per workgroup for every later launch, -1 = heuristic
+extern "C" int mvd_debug_set_attention_nw(int nw_log2) { g_attn_nw_override = nw_log2; return 0; }
 
 // out[2] = {waves per workgroup, workgroups} of the calling thread's last attention launch
 extern "C" int mvd_debug_last_attention_plan(int* out) {
@@ -960,6 +963,7 @@ int mvd_attention_pick_nw(const MvdAttnArgs& a) {
   const long heads_total = (long)a.heads * a.batch * a.nprob;
   static const int force = MVD_ENV_INT("MVD_ATTN_NW", -1);
   if (force >= 0) return force;
+  if (g_attn_nw_override >= 0) return g_attn_nw_override;
   if (maxq >= 128 && heads_total * ((maxq + 127) / 128) >= 512) return 2;
   if (maxq >= 64) return 1;
   return 0;

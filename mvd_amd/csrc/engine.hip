@@ -67,6 +67,9 @@ struct mvd_engine {
   int64_t ref_pixels(int h, int w) const { int64_t n = 0; for (auto& f : feats) n += (int64_t)(h >> f.level) * (w >> f.level); return n; }
   int64_t feat_pixel_off(int idx) const { int64_t n = 0; for (int i = 0; i < idx; ++i) n += (int64_t)(rc_h >> feats[i].level) * (rc_w >> feats[i].level); return n; }
   float* cam_emb = nullptr; int cam_batch = 0;
+  // arrival counters of the in-kernel split-K combine (gemm_sm.hip): one zeroed block per entry call, carved from the
+  // workspace, every split-K launch of the call takes its own slice (no counter is ever re-used inside a call)
+  unsigned int* cnt_base = nullptr; int cnt_used = 0, cnt_cap = 0;
   bool share_encoder = false;       // N4: the encoder pass reads weight set 0 (base UNet == image-encoder UNet)
   // hipGraph replay of whole forwards (mvd_engine_set_graph): one instantiated graph per distinct (arguments, cache state)
   struct HostState {                  // what a forward leaves behind on the host side
@@ -163,6 +166,27 @@ struct Ctx {
   }
   int gemm(MvdGemmArgs& g) {
     if (err) return err;
+    // small problems (one image's feature maps): the latency-oriented kernels of gemm_sm.hip, split-K combined in the kernel
+    static const bool use_sm = MVD_ENV_INT("MVD_GEMM_SM", 1) != 0;
+    int sm_tile = 0, sm_ns = 0, sm_S = 1;
+    if (use_sm && mvd_gemm_sm_plan(g, &sm_tile, &sm_ns, &sm_S)) {
+      const size_t mark = e->tmp.off;
+      if (sm_S > 1) {
+        g.splitk = sm_S; g.part = talloc<float>((size_t)sm_S * g.M * g.N);
+        const int tiles = ((g.M + 63) / 64) * (g.N / 64);           // (an upper bound for every tile shape)
+        g.tile_cnt = e->cnt_base + e->cnt_used;
+        e->cnt_used += tiles;
+        if (!dry && e->cnt_used > e->cnt_cap) { mvd_set_error("forward: split-K tile counters exhausted (%d > %d)", e->cnt_used, e->cnt_cap); return err = -15; }
+      }
+      int r = 0;
+      if (!dry) {
+        const double fl = 2.0 * g.M * (double)g.N * g.Ktot;
+        e->prof_M = g.M; e->prof_N = g.N; e->prof_K = g.Ktot; e->prof_tag = g.seg[0].mode * 100 + g.geglu * 10 + (sm_S > 1 ? sm_S : 0);
+        r = profiled(20 + sm_tile, fl, 0.0, [&] { return mvd_launch_gemm_sm(g, s, sm_tile, sm_ns); });
+      }
+      e->tmp.off = mark;
+      return r;
+    }
     // split-K for tile grids that cannot fill the chip: fp32 partials in scoped workspace + a reduce/epilogue pass
     const int S = mvd_gemm_pick_splitk(g);
     const size_t mark = e->tmp.off;
@@ -643,6 +667,17 @@ int camera_path(Ctx& c, const mvd_forward_args_t& a, std::unordered_map<std::str
   return c.err;
 }
 
+// Split-K arrival counters for one entry call: a block of the workspace, zeroed once (one memset node in front of the
+// call's first kernel); Ctx::gemm hands every split-K launch its own slice.
+constexpr int MVD_TILE_COUNTERS = 32768;
+int setup_tile_counters(mvd_engine* e, unsigned int* block, hipStream_t s, bool dry) {
+  e->cnt_base = block; e->cnt_used = 0; e->cnt_cap = MVD_TILE_COUNTERS;
+  if (dry) return 0;
+  hipError_t he = hipMemsetAsync(block, 0, MVD_TILE_COUNTERS * sizeof(unsigned int), s);
+  if (he != hipSuccess) { mvd_set_error("forward: hipMemsetAsync(tile counters): %s", hipGetErrorString(he)); return -3; }
+  return 0;
+}
+
 int forward_impl(mvd_engine* e, const mvd_forward_args_t& a, hipStream_t s, bool dry) {
   const mvd_config_t& cfg = e->cfg;
   if (a.batch <= 0 || a.height <= 0 || a.width <= 0 || a.text_len <= 0) { mvd_set_error("forward: bad shape"); return -1; }
@@ -668,6 +703,7 @@ int forward_impl(mvd_engine* e, const mvd_forward_args_t& a, hipStream_t s, bool
   e->tmp.off = e->tmp.high = 0;
   e->act.off = e->act.high = 0;
   Ctx c{e, s, 0, dry};
+  CHECK(setup_tile_counters(e, (unsigned int*)e->act.alloc(MVD_TILE_COUNTERS * sizeof(unsigned int)), s, dry));
   const int B = a.batch, H = a.height, Wd = a.width, L = a.text_len, xd = cfg.cross_attention_dim;
 
   // ---- persistent reference cache layout
@@ -751,6 +787,7 @@ int reference_finish_impl(mvd_engine* e, const float* mean_k, hipStream_t s, boo
   e->tmp.dry = dry;
   e->tmp.off = e->tmp.high = 0;
   Ctx c{e, s, 0, dry};
+  CHECK(setup_tile_counters(e, (unsigned int*)e->tmp.alloc(MVD_TILE_COUNTERS * sizeof(unsigned int)), s, dry));
   c.set = 0;                                         // the adapter's ref_kv weights live with the base set
   for (size_t i = 0; i < e->feats.size(); ++i) {
     const int lv = e->feats[i].level, C = e->feats[i].C;
@@ -1077,6 +1114,15 @@ int mvd_engine_get_camera_embedding(mvd_engine_t* e, float* out, void* stream) {
 }
 
 // ------------------------------------------------------------------ operator-level entry points
+// small-M kernels with split-K (force_cfg >= 100): the tile counters live behind the partials in the caller's split-K
+// workspace (MVD_OP_SPLITK_COUNTERS extra 4-byte words, zeroed here per call); the kernel combines the slices itself
+static int op_sm_splitk(MvdGemmArgs& g, hipStream_t s, int force_cfg) {
+  g.tile_cnt = reinterpret_cast<unsigned int*>(g.part + (size_t)g.splitk * g.M * g.N);
+  hipError_t e = hipMemsetAsync(g.tile_cnt, 0, MVD_OP_SPLITK_COUNTERS * sizeof(unsigned int), s);
+  if (e != hipSuccess) { mvd_set_error("op split-K: hipMemsetAsync: %s", hipGetErrorString(e)); return -3; }
+  if ((long)((g.M + 63) / 64) * (g.N / 64) > MVD_OP_SPLITK_COUNTERS) { mvd_set_error("op split-K: more than %d output tiles", MVD_OP_SPLITK_COUNTERS); return -1; }
+  return mvd_launch_gemm(g, s, force_cfg);
+}
 int mvd_op_linear(const void* a, const void* a2, int k1, int k2, const void* w, const float* bias, const float* rowvec,
                   int ld_rowvec, int rows_per_batch, const void* res, float alpha, int geglu, void* out, int out_f32, int m,
                   int n, int force_cfg, int splitk, float* splitk_ws, void* stream) {
@@ -1091,6 +1137,7 @@ int mvd_op_linear(const void* a, const void* a2, int k1, int k2, const void* w, 
   g.part = splitk_ws;      // (also the stamp buffer of probe builds)
   if (splitk > 1) {
     g.splitk = splitk; g.part = splitk_ws;
+    if (force_cfg >= 100) return op_sm_splitk(g, (hipStream_t)stream, force_cfg);
     if (int r = mvd_launch_gemm(g, (hipStream_t)stream, force_cfg)) return r;
     return mvd_launch_splitk_reduce(g, (hipStream_t)stream);
   }
@@ -1127,6 +1174,7 @@ int mvd_op_conv3x3(const void* x, int batch, int in_h, int in_w, int cin, int st
   g.part = splitk_ws;      // (also the stamp buffer of probe builds)
   if (splitk > 1) {
     g.splitk = splitk; g.part = splitk_ws;
+    if (force_cfg >= 100) return op_sm_splitk(g, (hipStream_t)stream, force_cfg);
     if (int r = mvd_launch_gemm(g, (hipStream_t)stream, force_cfg)) return r;
     return mvd_launch_splitk_reduce(g, (hipStream_t)stream);
   }

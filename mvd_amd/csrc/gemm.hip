@@ -645,6 +645,15 @@ int mvd_launch_gemm(const MvdGemmArgs& a, hipStream_t s, int force_cfg) {
   if (dbg) const_cast<MvdGemmArgs&>(a).dbg = dbg;
 #endif
   int cfg = force_cfg;
+  // force_cfg >= 100: the small-M kernels of gemm_sm.hip, 100 + 10 * tile + ring depth (0: default 4)
+  if (cfg >= 1000) { const_cast<MvdGemmArgs&>(a).w_blocked = 1; cfg -= 1000; }    // (+1000: W in the blocked LDS-image layout)
+  if (a.w_blocked && cfg < 100) { mvd_set_error("gemm: the blocked weight layout is read by the small-M kernels only"); return -1; }
+  if (cfg >= 100) {
+    const int tile = (cfg - 100) / 10, ns = (cfg - 100) % 10;
+    if (a.splitk > 1 && !a.tile_cnt) { mvd_set_error("gemm: the small-M kernels combine split-K in the kernel and need tile counters"); return -1; }
+    g_mvd_last_gemm.cfg = cfg; g_mvd_last_gemm.splitk = a.splitk > 1 ? a.splitk : 1;
+    return mvd_launch_gemm_sm(a, s, tile, ns ? ns : 4);
+  }
 #ifdef MVD_PROBE
   // probe builds only: force_cfg 15 = the ring-pipelined 256x320 experiment (gemm_ring.hip, not part of the product
   // library); MVD_GEMM_RING=1 routes every plain 256x320 launch to it

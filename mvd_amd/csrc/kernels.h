@@ -43,6 +43,9 @@ struct MvdGemmArgs {
   int out_f32;            // 1: fp32 output, else bf16
   int splitk;             // > 1: K is split over `splitk` work items per tile; raw fp32 partial tiles go to `part`
   float* part;            // [splitk][M][N] fp32 partials (then mvd_launch_splitk_reduce applies the epilogue)
+  int w_blocked;          // gemm_sm.hip only: W is stored as [N/32][K/64] blocks of 32 rows x 64 k in LDS-image order (packing.block_weight)
+  unsigned int* tile_cnt; // gemm_sm.hip split-K only: one ZEROED arrival counter per output tile (the slice that takes the last
+                          // ticket combines the partials in the kernel: no reduce launch)
   int dbg;                // probe builds only (-DMVD_PROBE, env MVD_GEMM_DEBUG): bit0 skip the output stores, bit1 skip the MFMAs
   // LayerNorm fold (ping-pong kernels only, see mvd_gemm_ln_fold_ok): A holds the UN-normalised rows x, W holds
   // W.diag(gamma), ln_c1[n] = sum_k W[n][k] (of the bf16 values), bias[n] = sum_k beta[k].W0[n][k] + b[n]; the kernel
@@ -66,6 +69,13 @@ bool mvd_gemm_ln_fold_ok(const MvdGemmArgs& a);
 int mvd_launch_gemm_pp(const MvdGemmArgs& a, hipStream_t s);
 // ring-pipelined 256x320 experiment (gemm_ring.hip, linked into probe builds only); arguments already validated by mvd_launch_gemm
 int mvd_launch_gemm_ring(const MvdGemmArgs& a, hipStream_t s);
+// small-M kernels (gemm_sm.hip): one work item per workgroup, NSTAGE-deep LDS-DMA ring, in-kernel split-K combine.
+// tile: 0..6 = 64x64, 128x64, 64x128, 128x128, 64x160, 128x160, 64x320; nstage: ring depth (clamped to 2..8 and to 160 KB of LDS)
+bool mvd_gemm_sm_applicable(const MvdGemmArgs& a, int tile);
+int mvd_launch_gemm_sm(const MvdGemmArgs& a, hipStream_t s, int tile, int nstage);
+// whether the engine should give this problem to the small-M kernels, and with which tile / ring depth / split-K
+bool mvd_gemm_sm_plan(const MvdGemmArgs& a, int* tile, int* nstage, int* splitk);
+#define MVD_OP_SPLITK_COUNTERS 4096   // tile counters behind the partials of an mvd_op_linear / mvd_op_conv3x3 split-K workspace
 // sum the split-K partials and apply the GEMM epilogue (bias, row vector, alpha, residual) -> out
 int mvd_launch_splitk_reduce(const MvdGemmArgs& a, hipStream_t s);
 // split factor the engine should use for this problem (1 = none); needs splitk*M*N floats of workspace

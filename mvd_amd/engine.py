@@ -283,7 +283,10 @@ class MVDEngine:
     PROFILE_CLASSES = {0: "gemm_256x160", 1: "gemm_256x128", 2: "gemm_128x160", 3: "gemm_128x128", 4: "gemm_128x64",
                        5: "gemm_64x64", 6: "gemm_pp_256x320_geglu", 7: "gemm_pp_256x320_dense", 8: "attn_1wave", 9: "attn_2wave", 10: "attn_4wave", 11: "attn_8wave",
                        12: "gemm_128x320", 13: "gemm_pp_256x320_conv3x3", 14: "gemm_pp_256x320_splitk", 15: "gemm_pp_256x320_ln_dense",
-                       16: "groupnorm", 17: "layernorm"}
+                       16: "groupnorm", 17: "layernorm",
+                       # small-M kernels (gemm_sm.hip), by tile
+                       20: "gemm_sm_64x64", 21: "gemm_sm_128x64", 22: "gemm_sm_64x128", 23: "gemm_sm_128x128", 24: "gemm_sm_64x160",
+                       25: "gemm_sm_128x160", 26: "gemm_sm_64x320"}
 
     def set_profiling(self, enable: bool):
         L.call("mvd_engine_set_profiling", self._h, int(enable))

@@ -40,7 +40,8 @@ def linear(a, w, bias=None, a2=None, rowvec=None, rows_per_batch=0, res=None, al
     assert w.shape[1] == k1 + k2
     on = n // 2 if geglu else n
     out = torch.empty(m, on, device=a.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
-    ws = torch.empty(splitk * m * n, device=a.device, dtype=torch.float32) if splitk > 1 else None
+    # (+ 4096 words: the tile counters of the small-M kernels' in-kernel split-K combine, MVD_OP_SPLITK_COUNTERS)
+    ws = torch.empty(splitk * m * n + 4096, device=a.device, dtype=torch.float32) if splitk > 1 else None
     L.call("mvd_op_linear", _p(a), _p(a2), k1, k2, _p(w), _p(bias), _p(rowvec),
            rowvec.shape[1] if rowvec is not None else 0, rows_per_batch, _p(res), float(alpha), int(geglu),
            _p(out), int(out_f32), m, n, force_cfg, splitk, _p(ws), _s())
@@ -70,7 +71,7 @@ def conv3x3(x, w_packed, bias=None, stride=1, upsample=False, rowvec=None, res=N
     out = torch.empty(B, oh, ow, cout, device=x.device, dtype=torch.bfloat16)
     c1 = shortcut.shape[-1] if shortcut is not None else 0
     c2 = shortcut2.shape[-1] if shortcut2 is not None else 0
-    ws = torch.empty(splitk * B * oh * ow * cout, device=x.device, dtype=torch.float32) if splitk > 1 else None
+    ws = torch.empty(splitk * B * oh * ow * cout + 4096, device=x.device, dtype=torch.float32) if splitk > 1 else None
     L.call("mvd_op_conv3x3", _p(x), B, H, W, Cin, stride, int(upsample), int(asym_pad), _p(w_packed), _p(bias), _p(rowvec),
            rowvec.shape[1] if rowvec is not None else 0, _p(res), _p(shortcut), _p(shortcut2), c1, c2, _p(out), cout,
            force_cfg, splitk, _p(ws), _s())

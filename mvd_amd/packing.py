@@ -45,6 +45,21 @@ def _conv_w(w: torch.Tensor, tap_major: bool = False) -> torch.Tensor:
     return w.reshape(co, ci // 64, 64, kh, kw).permute(0, 1, 3, 4, 2).reshape(co, kh * kw * ci)
 
 
+def block_weight(w: torch.Tensor) -> torch.Tensor:
+    """[N][K] (K contiguous) -> the blocked layout of the small-M kernels (gemm_sm.hip, ``MvdGemmArgs::w_blocked``):
+    [N/32][K/64] blocks of 32 rows x 128 bytes stored as the LDS image itself -- the 16-byte chunk ``c`` of row ``r`` sits in
+    slot ``c ^ ((r >> 1) & 7)`` -- so that one LDS-DMA instruction of a workgroup copies one contiguous 4 KB block and a work
+    item's K slice of a 32-row band is one contiguous range of HBM.  Same number of elements as ``w``."""
+    n, k = w.shape
+    assert n % 32 == 0 and k % 64 == 0, (n, k)
+    b = w.reshape(n // 32, 32, k // 64, 8, 8).permute(0, 2, 1, 3, 4)            # [nb][kb][row][chunk][8]
+    r = torch.arange(32, device=w.device)
+    slot = torch.arange(8, device=w.device)
+    src = slot[None, :] ^ ((r[:, None] >> 1) & 7)                               # chunk held by (row, slot)
+    idx = src[None, None, :, :, None].expand(n // 32, k // 64, 32, 8, 8)
+    return torch.gather(b, 3, idx).contiguous().reshape(n, k)
+
+
 def _geglu_rows(w: torch.Tensor) -> torch.Tensor:
     """[8C, ...] -> rows re-ordered so each block of 32 = 16 value rows then the 16 matching gate rows."""
     half = w.shape[0] // 2

@@ -293,3 +293,135 @@ def test_bad_shapes_are_rejected(ops):
     a, w = rnd(8, 64).cuda(), rnd(96, 64).cuda()         # N not a multiple of 64
     with pytest.raises(MvdError):
         ops.linear(a, w)
+
+
+# ------------------------------------------------------------------------------- small-M kernels (gemm_sm.hip, the batch-1 path)
+# force_cfg = 100 + 10 * tile + ring depth; tiles: 0 64x64, 1 128x64, 2 64x128, 3 128x128, 4 64x160, 5 128x160, 6 64x320
+SM_BN = {0: 64, 1: 64, 2: 128, 3: 128, 4: 160, 5: 160, 6: 320}
+
+
+@pytest.mark.parametrize("nstage", [2, 3, 4, 8])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("m,n,k", [(300, 640, 320), (1024, 1280, 192), (77, 640, 1024), (5, 1920, 64), (2100, 320, 128)])
+def test_sm_linear(ops, tile, nstage, m, n, k):
+    if n % SM_BN[tile]:
+        pytest.skip("N not divisible by this tile")
+    a, w = rnd(m, k, seed=1), rnd(n, k, scale=1 / math.sqrt(k), seed=2)
+    bias = rnd(n, seed=3, dtype=torch.float32)
+    want = a.float() @ w.float().T + bias
+    got = ops.linear(a.cuda(), w.cuda(), bias.cuda(), force_cfg=100 + 10 * tile + nstage)
+    close(got, want, what=f"sm linear tile{tile} ns{nstage}")
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6])
+def test_sm_linear_epilogues(ops, tile):
+    """two-source A, bias + per-batch row vector (tile inside one batch element and straddling two) + alpha + residual; fp32 out"""
+    for m, rpb in ((384, 128), (384, 96)):
+        n, k1, k2 = 640, 128, 192
+        a, a2 = rnd(m, k1, seed=1), rnd(m, k2, seed=2)
+        w = rnd(n, k1 + k2, scale=1 / math.sqrt(k1 + k2), seed=3)
+        bias = rnd(n, seed=4, dtype=torch.float32)
+        rowvec = rnd(m // rpb, n, seed=5, dtype=torch.float32)
+        res = rnd(m, n, seed=6)
+        want = 0.3 * (torch.cat([a, a2], 1).float() @ w.float().T + bias + rowvec.repeat_interleave(rpb, 0)) + res.float()
+        got = ops.linear(a.cuda(), w.cuda(), bias.cuda(), a2=a2.cuda(), rowvec=rowvec.cuda(), rows_per_batch=rpb,
+                         res=res.cuda(), alpha=0.3, force_cfg=100 + 10 * tile + 3)
+        close(got, want, what=f"sm tile{tile} dual-source+rowvec(rpb {rpb})+res+alpha")
+    got32 = ops.linear(a.cuda(), w[:, :k1].contiguous().cuda(), bias.cuda(), out_f32=True, force_cfg=100 + 10 * tile + 4)
+    close(got32, a.float() @ w[:, :k1].float().T + bias, tol=1e-4, what="sm linear fp32 out")
+
+
+@pytest.mark.parametrize("splitk", [2, 3, 5, 10])
+@pytest.mark.parametrize("tile", [0, 1, 3, 5, 6])
+def test_sm_splitk_in_kernel_combine(ops, tile, splitk):
+    """Split-K combined inside the kernel (last-arriving slice sums the write-through partials in slice order): same epilogue
+    as the unsplit form, and two launches give the same bits (the combine order does not depend on who arrives last)."""
+    m, n, k, rpb = 200, 640, 640, 100
+    a, w = rnd(m, k, seed=1), rnd(n, k, scale=1 / math.sqrt(k), seed=2)
+    bias, rowvec, res = rnd(n, seed=3, dtype=torch.float32), rnd(m // rpb, n, seed=4, dtype=torch.float32), rnd(m, n, seed=5)
+    want = (a.float() @ w.float().T + bias + rowvec.repeat_interleave(rpb, 0)) + res.float()
+    args = (a.cuda(), w.cuda(), bias.cuda())
+    kw = dict(rowvec=rowvec.cuda(), rows_per_batch=rpb, res=res.cuda(), force_cfg=100 + 10 * tile + 3, splitk=splitk)
+    got = ops.linear(*args, **kw)
+    close(got, want, what=f"sm linear tile{tile} splitk={splitk}")
+    for _ in range(3):
+        assert torch.equal(got, ops.linear(*args, **kw)), "split-K combine is not bit-deterministic"
+    B, H, W, cin, cout = 2, 6, 6, 128, 640
+    x = rnd(B, cin, H, W, seed=6)
+    wc = rnd(cout, cin, 3, 3, scale=1 / math.sqrt(9 * cin), seed=7)
+    want = F.conv2d(x.float(), wc.float(), bias[:cout], padding=1).permute(0, 2, 3, 1)
+    got = ops.conv3x3(x.permute(0, 2, 3, 1).contiguous().cuda(), _pack(wc).cuda(), bias[:cout].contiguous().cuda(),
+                      force_cfg=100 + 10 * tile + 4, splitk=splitk)
+    close(got, want, what=f"sm conv tile{tile} splitk={splitk}")
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 6])
+def test_sm_geglu(ops, tile):
+    from mvd_amd.packing import _geglu_rows
+    m, c = 300, 320
+    a = rnd(m, c, seed=1)
+    w = rnd(8 * c, c, scale=1 / math.sqrt(c), seed=2)
+    bias = rnd(8 * c, seed=3, dtype=torch.float32)
+    val, gate = (a.float() @ w.float().T + bias).chunk(2, -1)
+    got = ops.linear(a.cuda(), _geglu_rows(w).contiguous().cuda(), _geglu_rows(bias).contiguous().cuda(), geglu=True,
+                     force_cfg=100 + 10 * tile + 3)
+    close(got, val * F.gelu(gate), what=f"sm geglu tile{tile}")
+
+
+@pytest.mark.parametrize("tile", [0, 1, 3, 4, 5, 6])
+@pytest.mark.parametrize("stride,ups,asym", [(1, False, False), (2, False, False), (1, True, False), (2, False, True)])
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 16, 16, 64, 128), (1, 8, 12, 192, 64), (3, 6, 6, 128, 320)])
+def test_sm_conv3x3(ops, stride, ups, asym, B, H, W, cin, cout, tile):
+    if cout % SM_BN[tile]:
+        pytest.skip("N not divisible by this tile")
+    x = rnd(B, cin, H, W, seed=1)
+    w = rnd(cout, cin, 3, 3, scale=1 / math.sqrt(9 * cin), seed=2)
+    bias = rnd(cout, seed=3, dtype=torch.float32)
+    xin = x.float()
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    if asym:
+        want = F.conv2d(F.pad(xin, (0, 1, 0, 1)), w.float(), bias, stride=2, padding=0).permute(0, 2, 3, 1)
+    else:
+        want = F.conv2d(xin, w.float(), bias, stride=stride, padding=1).permute(0, 2, 3, 1)
+    got = ops.conv3x3(x.permute(0, 2, 3, 1).contiguous().cuda(), _pack(w).cuda(), bias.cuda(), stride=stride, upsample=ups,
+                      asym_pad=asym, force_cfg=100 + 10 * tile + 3)
+    close(got, want, what=f"sm conv3x3 s{stride} ups{ups} asym{asym} tile{tile}")
+
+
+@pytest.mark.parametrize("tile", [0, 1, 3, 4, 5, 6])
+def test_sm_conv3x3_resnet_fusions(ops, tile):
+    """conv1 (+time-embedding row vector) and conv2 (+1x1 shortcut over a 2-source concat / + residual), also split over K."""
+    B, H, W, c0, c1, cout = 2, 8, 8, 128, 64, 320
+    if cout % SM_BN[tile]:
+        pytest.skip("N not divisible by this tile")
+    x0, x1 = rnd(B, c0, H, W, seed=1), rnd(B, c1, H, W, seed=2)
+    h = rnd(B, cout, H, W, seed=3)
+    w2 = rnd(cout, cout, 3, 3, scale=1 / math.sqrt(9 * cout), seed=4)
+    wsc = rnd(cout, c0 + c1, 1, 1, scale=1 / math.sqrt(c0 + c1), seed=5)
+    bias = rnd(cout, seed=6, dtype=torch.float32)
+    temb = rnd(B, cout, seed=7, dtype=torch.float32)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()  # noqa: E731
+    wp = torch.cat([_pack(w2), wsc.reshape(cout, c0 + c1)], 1).contiguous()
+    for sk in (1, 4):
+        want = F.conv2d(h.float(), w2.float(), bias, padding=1) + F.conv2d(torch.cat([x0, x1], 1).float(), wsc.float())
+        got = ops.conv3x3(nhwc(h), wp.cuda(), bias.cuda(), shortcut=nhwc(x0), shortcut2=nhwc(x1), force_cfg=100 + 10 * tile + 4, splitk=sk)
+        close(got, want.permute(0, 2, 3, 1), what=f"sm conv2+shortcut splitk {sk}")
+        want = F.conv2d(h.float(), w2.float(), bias, padding=1) + temb[:, :, None, None] + h.float()
+        got = ops.conv3x3(nhwc(h), _pack(w2).cuda(), bias.cuda(), rowvec=temb.cuda(), res=nhwc(h), force_cfg=100 + 10 * tile + 4, splitk=sk)
+        close(got, want.permute(0, 2, 3, 1), what=f"sm conv+temb+residual splitk {sk}")
+
+
+def test_rows_beyond_m_are_never_written(ops):
+    """Every GEMM form on a ragged M: the rows behind the output (a guard region of the same allocation) stay untouched."""
+    m, n, k = 300, 640, 320
+    a, w = rnd(m, k, seed=1).cuda(), rnd(n, k, scale=1 / math.sqrt(k), seed=2).cuda()
+    import ctypes as C
+    from mvd_amd import _lib as L
+    for cfg in (-1, 7, 10, 13, 103, 133, 153, 163):
+        buf = torch.full((m + 600, n), 7.0, device="cuda", dtype=torch.bfloat16)
+        L.call("mvd_op_linear", C.c_void_p(a.data_ptr()), None, k, 0, C.c_void_p(w.data_ptr()), None, None, 0, 0, None, 1.0, 0,
+               C.c_void_p(buf.data_ptr()), 0, m, n, cfg, 1, None, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        assert bool((buf[m:] == 7.0).all()), f"cfg {cfg} wrote rows >= M"
+        close(buf[:m], a.float().cpu() @ w.float().cpu().T, what=f"cfg {cfg}")
