@@ -247,6 +247,7 @@ def main():
     ap.add_argument("--shapes-out", default="", help="write the per-shape kernel table of the profiled steps to this file")
     ap.add_argument("--latent", type=int, default=64, help="latent height = width (64 = 512x512 images, 96 = the reference's 768x768 default, infer.py:187)")
     ap.add_argument("--attn-nw", type=int, default=-1, help="measurement: force log2(waves per attention workgroup)")
+    ap.add_argument("--debug-flags", type=int, default=0, help="measurement: mvd_debug_set_flags bits")
     ap.add_argument("--launch-dry-run", action="store_true",
                     help="control flow only (no GPU, gloo): process group, a small arena broadcast, barriers, max over ranks, rank 0's line")
     args = ap.parse_args()
@@ -312,6 +313,9 @@ def main():
     model._dirty = False
     torch.cuda.empty_cache()
 
+    if args.debug_flags:
+        from mvd_amd import _lib as _L
+        _L.lib().mvd_debug_set_flags(args.debug_flags)
     if args.attn_nw >= 0:
         from mvd_amd import _lib as _L
         _L.lib().mvd_debug_set_attention_nw(args.attn_nw)

@@ -98,6 +98,7 @@ _SIGS = {
     "mvd_debug_pick_splitk": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "mvd_gemm_sm_num_tiles": (C.c_int, []),
     "mvd_debug_set_attention_nw": (C.c_int, [C.c_int]),
+    "mvd_debug_set_flags": (C.c_int, [C.c_int]),
     "mvd_op_ddpm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float,
                                    C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
     "mvd_op_cfg_combine": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),

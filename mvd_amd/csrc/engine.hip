@@ -20,6 +20,11 @@
 
 int mvd_launch_silu_to_bf16(const float* x, int64_t n, bf16_t* y, hipStream_t s);
 
+// measurement / bisection switches (bench.py --debug-flags, tools/): bit 0 = no LayerNorm fold through the small-M kernels,
+// bit 1 = small-M kernels never split K, bit 2 = small-M kernels off
+static int g_debug_flags = 0;
+extern "C" int mvd_debug_set_flags(int flags) { g_debug_flags = flags; return 0; }
+
 namespace {
 
 struct Weight { const void* p; int64_t numel; int dtype; };
@@ -169,7 +174,8 @@ struct Ctx {
     // small problems (one image's feature maps): the latency-oriented kernels of gemm_sm.hip, split-K combined in the kernel
     static const bool use_sm = MVD_ENV_INT("MVD_GEMM_SM", 1) != 0;
     int sm_tile = 0, sm_ns = 0, sm_S = 1;
-    if (use_sm && mvd_gemm_sm_plan(g, &sm_tile, &sm_ns, &sm_S)) {
+    if (use_sm && !(g_debug_flags & 4) && mvd_gemm_sm_plan(g, &sm_tile, &sm_ns, &sm_S)) {
+      if (g_debug_flags & 2) sm_S = 1;
       const size_t mark = e->tmp.off;
       if (sm_S > 1) {
         g.splitk = sm_S; g.part = talloc<float>((size_t)sm_S * g.M * g.N);
@@ -224,7 +230,14 @@ struct Ctx {
     g.ldw = C; g.seg[0].p0 = x; g.seg[0].c0 = C; g.seg[0].mode = MVD_A_DENSE; g.seg[0].ksize = C; g.nseg = 1;
     g.M = M; g.N = N; g.Ktot = C; g.rows_per_batch = M; g.outH = 1; g.outW = M; g.alpha = 1.f; g.geglu = geglu; g.out = out; g.ldo = ldo;
     static const bool use_fold = MVD_ENV_INT("MVD_LN_FOLD", 1) != 0;
-    if (use_fold && !dry && has(slot + ".wf") && has(slot + ".cf") && mvd_gemm_ln_fold_ok(g)) {
+    auto sm_fold_ok = [&]() {      // the small-M kernels (batch 1) fold at every level
+      MvdGemmArgs t = g;
+      static const float dummy = 0.f;
+      t.ln_c1 = &dummy; t.bias = &dummy; t.W = reinterpret_cast<const bf16_t*>(&dummy);
+      int a_, b_, c_;
+      return !(g_debug_flags & 5) && mvd_gemm_sm_plan(t, &a_, &b_, &c_);
+    };
+    if (use_fold && !dry && has(slot + ".wf") && has(slot + ".cf") && (mvd_gemm_ln_fold_ok(g) || sm_fold_ok())) {
       const float* cf = WF(slot + ".cf", 2 * n_full);
       g.W = WB(slot + ".wf", n_full * C);
       g.ln_c1 = cf; g.bias = cf ? cf + n_full : nullptr; g.ln_eps = 1e-5f;
@@ -1151,7 +1164,12 @@ int mvd_op_ln_linear(const void* x, int k, const void* w_folded, const float* c1
   g.W = (const bf16_t*)w_folded; g.M = m; g.N = n; g.Ktot = k; g.ldw = k; g.rows_per_batch = m; g.outH = 1; g.outW = m;
   g.bias = c2; g.ln_c1 = c1; g.ln_eps = eps; g.alpha = 1.f; g.geglu = geglu; g.out = out; g.ldo = geglu ? n / 2 : n; g.ldres = g.ldo;
   if (!c1 || !c2) { mvd_set_error("mvd_op_ln_linear: c1 and c2 are required"); return -1; }
-  if (!mvd_gemm_ln_fold_ok(g)) { mvd_set_error("mvd_op_ln_linear: M=%d N=%d K=%d geglu=%d is not a shape of the fused LayerNorm GEMM (mvd_gemm_ln_fold_ok)", m, n, k, geglu); return -1; }
+  if (!mvd_gemm_ln_fold_ok(g)) {
+    int tile = 0, ns = 0, S = 1;           // small problems (batch 1): the fold of the small-M kernels
+    if (mvd_gemm_sm_plan(g, &tile, &ns, &S) && S == 1) return mvd_launch_gemm_sm(g, (hipStream_t)stream, tile, ns);
+    mvd_set_error("mvd_op_ln_linear: M=%d N=%d K=%d geglu=%d is not a shape of the fused LayerNorm GEMMs", m, n, k, geglu);
+    return -1;
+  }
   return mvd_launch_gemm(g, (hipStream_t)stream);
 }
 

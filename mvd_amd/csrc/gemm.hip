@@ -632,7 +632,7 @@ int mvd_launch_gemm(const MvdGemmArgs& a, hipStream_t s, int force_cfg) {
   if (a.ldw < a.Ktot || (a.ldw % 8) || !a.W) { mvd_set_error("gemm: bad weight stride ldw=%d (K=%d)", a.ldw, a.Ktot); return -1; }
   if (a.rows_per_batch <= 0) { mvd_set_error("gemm: rows_per_batch must be > 0"); return -1; }
   if (a.N % 64) { mvd_set_error("gemm: N=%d must be a multiple of 64", a.N); return -1; }
-  if (a.splitk > 1 && (!a.part || a.geglu || a.splitk > 16 || a.splitk > a.Ktot / 64)) { mvd_set_error("gemm: bad split-K request (splitk=%d)", a.splitk); return -1; }
+  if (a.splitk > 1 && (!a.part || a.geglu || a.splitk > (force_cfg >= 100 ? 64 : 16) || a.splitk > a.Ktot / 64)) { mvd_set_error("gemm: bad split-K request (splitk=%d)", a.splitk); return -1; }
   if (a.geglu && (a.out_f32 || a.res || a.rowvec)) { mvd_set_error("gemm: unsupported GEGLU epilogue combination"); return -1; }
   const int on = a.geglu ? a.N / 2 : a.N;
   if (a.ldo < on || (a.ldo % 4) || (a.res && (a.ldres % 4))) { mvd_set_error("gemm: bad leading dims"); return -1; }

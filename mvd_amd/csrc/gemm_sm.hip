@@ -13,10 +13,11 @@
 //   waited for, one raw s_barrier per slab, counted vmcnt (the DMAs of the next NSTAGE-2 slabs stay in flight across it).
 //   NSTAGE is a launch parameter (ring bytes = dynamic LDS), so K = 320 keeps the whole operand in flight at once.
 // * bias / row vector / residual are fetched in the prologue, under the first slabs' latency, not after the last MFMA.
-// * Split-K combines IN the kernel: every slice stores its fp32 partial tile write-through (sc1), one lane takes a ticket on a
-//   per-tile counter, the slice that draws the last ticket sums the partials in slice order (bit-deterministic whoever
-//   arrives last) and runs the ordinary epilogue -- no reduce launch (the agent-scope hand-off of the CDNA4 guide: sc1
-//   stores + vmcnt(0) + barrier + one relaxed agent atomic; the reducer reads with sc1 loads, no fence).
+// * Split-K combines IN the kernel: every slice stores its fp32 partial tile write-through (sc1) and arrives on a per-tile
+//   counter; the tile's slices wait for each other (they are all resident: the grid never exceeds what the chip holds) and
+//   EVERY slice then sums a share of the tile's 16x16 sub-tiles over the slices, in slice order (bit-deterministic), and runs
+//   the epilogue on it -- no reduce launch, no serial tail through one workgroup (the agent-scope hand-off of the CDNA4
+//   guide: sc1 stores + vmcnt(0) + barrier + one relaxed agent atomic, sc1-load poll, sc1 loads of the partials, no fence).
 // * Operand layouts, the LDS image (128-byte rows, 16-byte chunks XOR-swizzled by (row >> 1) & 7 on the SOURCE side) and
 //   the MFMA roles (W rows feed the "A" operand of v_mfma_f32_16x16x32_bf16: a lane ends up with four consecutive output
 //   channels of one row) are those of gemm.hip.
@@ -53,7 +54,10 @@ constexpr int SM_MAX_STAGES = 8;
 
 // 256 threads = 4 waves as 2 x 2; wave tile (BM/2) x (BN/2).  AMODE: 0 dense A (1-2 sources), 1 implicit 3x3 conv (stride 1/2,
 // fused nearest-2x upsample, bottom/right-only padding), 2 conv followed by a dense (1x1 shortcut) K segment.
-template <int BM, int BN, int AMODE, bool SPLITK, bool GEGLU>
+// LNF: LayerNorm of the A rows folded in (MvdGemmArgs::ln_c1, as gemm_pp.hip: W carries gamma, out = rstd[m] * (acc - mean[m] *
+// c1[n]) + c2[n]); the row sums / sums of squares are accumulated from the A fragments the MFMAs consume -- the two waves
+// that share a row block take every other row tile each and trade (rstd, -rstd * mean) through LDS behind the ring.
+template <int BM, int BN, int AMODE, bool SPLITK, bool GEGLU, bool LNF = false>
 __global__ __launch_bounds__(256) void gemm_sm_kernel(const MvdGemmArgs a, const int nstage) {
   constexpr int WTM = BM / 2, WTN = BN / 2, TM = WTM / 16, TN = WTN / 16;
   constexpr int A_IT = BM / 32, B_IT = BN / 32, L = A_IT + B_IT;          // LDS-DMA instructions per wave per slab
@@ -61,6 +65,8 @@ __global__ __launch_bounds__(256) void gemm_sm_kernel(const MvdGemmArgs a, const
   constexpr bool HAS_CONV = AMODE != 0;
   static_assert(WTM % 16 == 0 && WTN % 16 == 0 && BM % 32 == 0 && BN % 32 == 0, "tile shape");
   static_assert(!GEGLU || (TN % 2 == 0 && AMODE == 0 && !SPLITK), "GEGLU: value/gate column tiles pair up inside a wave");
+  static_assert(!LNF || (AMODE == 0 && !SPLITK), "the LayerNorm fold is a dense, unsplit form");
+  constexpr int TS = LNF ? TM : 1;                                         // row tiles whose (half-K) statistics this wave accumulates
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -186,7 +192,7 @@ __global__ __launch_bounds__(256) void gemm_sm_kernel(const MvdGemmArgs a, const
   const int nb = n0 + wn * WTN + fq * 4;                 // this lane's first column inside column tile 0 of the wave
   const bool final_here = !SPLITK;                       // (SPLITK: the reducer fetches the epilogue operands itself)
   const bool tile_rv = !GEGLU && a.rowvec && a.rows_per_batch % BM == 0;   // the tile lies inside one batch element
-  f32x4 cb[TN], rvv[GEGLU ? 1 : TN];
+  f32x4 cb[TN], rvv[GEGLU ? 1 : TN], c1v[LNF ? TN : 1];
 #pragma unroll
   for (int j = 0; j < TN; ++j) cb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   constexpr int RN = GEGLU ? 1 : TN;
@@ -195,6 +201,10 @@ __global__ __launch_bounds__(256) void gemm_sm_kernel(const MvdGemmArgs a, const
     if (a.bias) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) cb[j] = *reinterpret_cast<const f32x4*>(a.bias + nb + j * 16);
+    }
+    if constexpr (LNF) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) c1v[j] = *reinterpret_cast<const f32x4*>(a.ln_c1 + nb + j * 16);
     }
     if (tile_rv) {
       const float* rv = a.rowvec + (size_t)(m0 / a.rows_per_batch) * a.ld_rowvec + nb;
@@ -224,6 +234,9 @@ __global__ __launch_bounds__(256) void gemm_sm_kernel(const MvdGemmArgs a, const
 
   // ---- main loop: slab t lives in ring stage t % NSTAGE.  One barrier per slab: behind it every wave's DMAs of slab t have
   // landed (each waited for its own) and every wave has finished reading slab t-1, whose stage the next request re-fills.
+  float row_s[TS], row_q[TS];
+#pragma unroll
+  for (int q = 0; q < TS; ++q) { row_s[q] = 0.f; row_q[q] = 0.f; }
   const int frag_off = fr * 128 + ((fq ^ ((fr >> 1) & 7)) << 4);
   int st = 0, st_fill = pre == nstage - 1 ? nstage - 1 : 0;
   for (int t = 0; t < nk; ++t) {
@@ -252,6 +265,26 @@ __global__ __launch_bounds__(256) void gemm_sm_kernel(const MvdGemmArgs a, const
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+      if constexpr (LNF) {
+        // The two waves of a row block split the statistics by k HALF (wave wn takes the 32-deep half wn of every slab, all TM
+        // row tiles): every register index stays a compile-time constant.  (Splitting by row tile -- af[2 q + wn] -- made hipcc
+        // index the fragment array dynamically through scratch memory.)  This lane: 8 of the half's 32 k of row fr.
+        if (half == wn) {
+          typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+          const bf16x2_t ones = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
+#pragma unroll
+          for (int q = 0; q < TM; ++q) {
+            const u32x4 x4 = __builtin_bit_cast(u32x4, af[q]);
+            const unsigned dw[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const bf16x2_t x = __builtin_bit_cast(bf16x2_t, dw[e]);
+              row_q[q] = __builtin_amdgcn_fdot2_f32_bf16(x, x, row_q[q], false);
+              row_s[q] = __builtin_amdgcn_fdot2_f32_bf16(x, ones, row_s[q], false);
+            }
+          }
+        }
+      }
     }
     st = st + 1 == nstage ? 0 : st + 1;
   }
@@ -277,39 +310,92 @@ __global__ __launch_bounds__(256) void gemm_sm_kernel(const MvdGemmArgs a, const
       }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // every storing wave drains its own stores
     __builtin_amdgcn_s_barrier();
-    unsigned* flag = reinterpret_cast<unsigned*>(smem);                 // (the one LDS array; the ring is dead by now)
-    if (tid == 0) *flag = __hip_atomic_fetch_add(a.tile_cnt + tl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // Rendezvous of the tile's S slices (all resident: the launcher admits no grid beyond what the chip holds at once), then
+    // EVERY slice combines a share of the tile: the 16x16 sub-tiles are dealt round-robin to the 4 S waves, a wave sums its
+    // sub-tile over the slices in slice order (S loads in flight per lane, one memory round trip) and runs the epilogue on
+    // it.  A last-arriver combine would read S x tile bytes through ONE workgroup after everybody else has left.
+    int* flag = reinterpret_cast<int*>(smem);                           // (the one LDS array; the ring is dead by now)
+    if (tid == 0) {
+      typedef __attribute__((address_space(1))) unsigned int gu32;
+      gu32* c = (gu32*)(a.tile_cnt + tl);
+      __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int spins = 0, ok = 1;
+      while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)S) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1 << 20)) { ok = 0; break; }                     // bounded: a give-up poisons the output (loud, not hung)
+      }
+      *flag = ok;
+    }
     __syncthreads();
-    if (*flag != (unsigned)(S - 1)) return;
-    fetch_epilogue_operands();
+    const bool gave_up = *flag == 0;
+    constexpr int UN = BN / 16, U = (BM / 16) * UN;                     // 16x16 sub-tiles of the tile
+    const float alpha_s = a.alpha;
+    for (int u = ks * 4 + wave; u < U; u += 4 * S) {
+      const int ti = u / UN, tj = u - ti * UN;
+      const int m = m0 + ti * 16 + fr, n = n0 + tj * 16 + fq * 4;
+      const bool live = m < a.M;
+      const unsigned vo = live ? (unsigned)(((size_t)m * a.N + n) * 4) : OOB;
+      // epilogue operands of this sub-tile first (plain loads of tensors nobody writes in this launch)
+      f32x4 add = f32x4{0.f, 0.f, 0.f, 0.f};
+      u32x2 rr = {0u, 0u};
+      const int mc = live ? m : a.M - 1;
+      if (a.bias) add = *reinterpret_cast<const f32x4*>(a.bias + n);
+      f32x4 rvv2 = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (a.rowvec) rvv2 = *reinterpret_cast<const f32x4*>(a.rowvec + (size_t)(mc / a.rows_per_batch) * a.ld_rowvec + n);
+      if (a.res) rr = *reinterpret_cast<const u32x2*>(a.res + (size_t)mc * a.ldres + n);
+      f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int s0 = 0; s0 < S; s0 += 8) {
+        u32x4 p[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int sq = s0 + q < S ? s0 + q : S - 1;                  // (beyond S: re-read the last slice, not added)
+          p[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_p, (int)vo, (int)((size_t)sq * slab * 4), 16);   // sc1: not from this CU's L1
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (s0 + q < S) sum += __builtin_bit_cast(f32x4, p[q]);
+      }
+      f32x4 v = (sum + add + rvv2) * alpha_s;
+      if (a.res) { v[0] += bflo(rr[0]); v[1] += bfhi(rr[0]); v[2] += bflo(rr[1]); v[3] += bfhi(rr[1]); }
+      if (gave_up) v = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+      if (!live) continue;
+      if (a.out_f32) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + (size_t)m * a.ldo + n) = v;
+      } else {
+        const u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.ldo + n) = o;
+      }
+    }
+    return;
+  }
+
+  // ---- LNF: finish the row statistics.  The four lanes fr, fr + 16, fr + 32, fr + 48 hold the k quarters of a row's half; the
+  // two waves of a row block trade their halves through the exchange area behind the ring ([k half][row of the tile] ->
+  // (sum, sum of squares)) and both finish (rstd, -rstd * mean) in the same order: half 0 + half 1.
+  float2 lnst[LNF ? TM : 1];
+  if constexpr (LNF) {
+    float2* xch = reinterpret_cast<float2*>(smem + nstage * STAGE_BYTES);
+#pragma unroll
+    for (int q = 0; q < TM; ++q) {
+      float sm = row_s[q], sq = row_q[q];
+      sm += __shfl_xor(sm, 16); sq += __shfl_xor(sq, 16);
+      sm += __shfl_xor(sm, 32); sq += __shfl_xor(sq, 32);
+      if (fq == 0) xch[wn * BM + wm * WTM + q * 16 + fr] = float2{sm, sq};
+    }
+    __syncthreads();
+    const float invk = 1.f / (float)a.Ktot;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const float2 p0 = xch[wm * WTM + i * 16 + fr], p1 = xch[BM + wm * WTM + i * 16 + fr];
+      const float mean = (p0.x + p1.x) * invk;
+      const float var = fmaxf((p0.y + p1.y) * invk - mean * mean, 0.f);
+      const float sc = rsqrtf(var + a.ln_eps);
+      lnst[i] = float2{sc, -sc * mean};
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // slice order, every slice read back from memory (sc1: not from this CU's L1); SB slices are requested at a time -- a
-    // slice-by-slice loop is S dependent memory round trips, and the other workgroups of the tile have already left
-    constexpr int SB = TM * TN <= 4 ? 4 : (TM * TN <= 8 ? 2 : 1);
-    for (int s0 = 0; s0 < S; s0 += SB) {
-      u32x4 p[SB][TM][TN];
-#pragma unroll
-      for (int q = 0; q < SB; ++q) {
-        // (slices beyond S re-read the last one and are not added: the loads stay unconditional, no branch per load)
-        const int sq = s0 + q < S ? s0 + q : S - 1;
-        const unsigned so = (unsigned)((size_t)sq * slab * 4);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) p[q][i][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_p, (int)pvo[i] + j * 64, (int)so, 16);
-      }
-#pragma unroll
-      for (int q = 0; q < SB; ++q) {
-        const float keep = s0 + q < S ? 1.f : 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] += __builtin_bit_cast(f32x4, p[q][i][j]) * keep;
-      }
-    }
+      for (int j = 0; j < TN; ++j) acc[i][j] = acc[i][j] * lnst[i].x + c1v[j] * lnst[i].y;     // (+ c2 = cb below)
   }
 
   // ---- epilogue
@@ -353,13 +439,14 @@ struct SmTile { int bm, bn; };
 const SmTile kSmTiles[] = {{64, 64}, {128, 64}, {64, 128}, {128, 128}, {64, 160}, {128, 160}, {64, 320}};
 constexpr int kNumSmTiles = 7;
 
-template <int BM, int BN, int AMODE, bool SPLITK, bool GEGLU>
+template <int BM, int BN, int AMODE, bool SPLITK, bool GEGLU, bool LNF = false>
 int launch_sm3(const MvdGemmArgs& a, int nstage, hipStream_t s) {
   constexpr int STAGE_BYTES = (BM + BN) * 128;
-  const int lds = nstage * STAGE_BYTES;
+  if (LNF && nstage * STAGE_BYTES + BM * 16 > 160 * 1024) --nstage;
+  const int lds = nstage * STAGE_BYTES + (LNF ? BM * 16 : 0);
   static int lds_set = 0;
   if (lds > lds_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_sm_kernel<BM, BN, AMODE, SPLITK, GEGLU>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_sm_kernel<BM, BN, AMODE, SPLITK, GEGLU, LNF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { mvd_set_error("gemm_sm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return -2; }
     lds_set = 160 * 1024;
@@ -367,8 +454,25 @@ int launch_sm3(const MvdGemmArgs& a, int nstage, hipStream_t s) {
   const int ntm = (a.M + BM - 1) / BM, ntn = a.N / BN;
   const int S = a.splitk > 1 ? a.splitk : 1;
   const int grid = ntm * ntn * S;
+  if (S > 1) {
+    // the slices of a tile wait for each other inside the kernel: every workgroup of the grid must be resident at once
+    static int occ_lds = -1, occ = 0;
+    if (occ_lds != lds) {
+      int nb = 0;
+      hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_sm_kernel<BM, BN, AMODE, SPLITK, GEGLU, LNF>, 256, lds);
+      occ = (e == hipSuccess && nb > 0) ? nb : 1;
+      occ_lds = lds;
+    }
+    static int ncu = 0;
+    if (!ncu) {
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+    }
+    if (grid > occ * ncu) { mvd_set_error("gemm_sm: a split-K grid of %d workgroups exceeds the %d the chip holds at once (ring %d bytes)", grid, occ * ncu, lds); return -1; }
+  }
   g_mvd_last_gemm.tiles = grid; g_mvd_last_gemm.grid = grid; g_mvd_last_gemm.per_cu = 160 * 1024 / lds;
-  hipLaunchKernelGGL((gemm_sm_kernel<BM, BN, AMODE, SPLITK, GEGLU>), dim3(grid), dim3(256), lds, s, a, nstage);
+  hipLaunchKernelGGL((gemm_sm_kernel<BM, BN, AMODE, SPLITK, GEGLU, LNF>), dim3(grid), dim3(256), lds, s, a, nstage);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { mvd_set_error("gemm_sm launch: %s", hipGetErrorString(e)); return -3; }
   return 0;
@@ -378,9 +482,10 @@ template <int BM, int BN>
 int launch_sm2(const MvdGemmArgs& a, int nstage, hipStream_t s) {
   const bool sk = a.splitk > 1;
   if (a.geglu) {
-    if constexpr ((BN / 32) % 2 == 0) return launch_sm3<BM, BN, 0, false, true>(a, nstage, s);
+    if constexpr ((BN / 32) % 2 == 0) return a.ln_c1 ? launch_sm3<BM, BN, 0, false, true, true>(a, nstage, s) : launch_sm3<BM, BN, 0, false, true>(a, nstage, s);
     else { mvd_set_error("gemm_sm: GEGLU needs an even number of 16-column tiles per wave"); return -1; }
   }
+  if (a.ln_c1) return launch_sm3<BM, BN, 0, false, false, true>(a, nstage, s);
   if (a.seg[0].mode == MVD_A_DENSE) return sk ? launch_sm3<BM, BN, 0, true, false>(a, nstage, s) : launch_sm3<BM, BN, 0, false, false>(a, nstage, s);
   if (a.nseg == 1) return sk ? launch_sm3<BM, BN, 1, true, false>(a, nstage, s) : launch_sm3<BM, BN, 1, false, false>(a, nstage, s);
   return sk ? launch_sm3<BM, BN, 2, true, false>(a, nstage, s) : launch_sm3<BM, BN, 2, false, false>(a, nstage, s);
@@ -392,7 +497,11 @@ int launch_sm2(const MvdGemmArgs& a, int nstage, hipStream_t s) {
 bool mvd_gemm_sm_applicable(const MvdGemmArgs& a, int tile) {
   if (tile < 0 || tile >= kNumSmTiles) return false;
   const size_t lim = (size_t)1 << 31;
-  if (a.N % kSmTiles[tile].bn || a.Ktot % 64 || a.ln_c1) return false;
+  if (a.N % kSmTiles[tile].bn || a.Ktot % 64) return false;
+  if (a.ln_c1) {   // LayerNorm fold: one dense source spanning the whole row, a bias (c2), no residual / row vector / split-K
+    const MvdASeg& g = a.seg[0];
+    if (a.nseg != 1 || g.mode != MVD_A_DENSE || g.c1 || a.splitk > 1 || a.res || a.rowvec || a.out_f32 || !a.bias || a.Ktot != g.c0) return false;
+  }
   if (a.w_blocked && a.ldw != a.Ktot) return false;
   if (a.geglu && ((kSmTiles[tile].bn / 32) % 2 || a.splitk > 1 || a.seg[0].mode != MVD_A_DENSE)) return false;
   if ((size_t)a.N * a.ldw * 2 >= lim) return false;
@@ -421,7 +530,7 @@ extern "C" int mvd_gemm_sm_num_tiles(void) { return kNumSmTiles; }
 //   operand is the traffic (convolutions at 32x32 and 16x16: 64x160 / 64x128, the activation slab is re-read per column tile).
 bool mvd_gemm_sm_plan(const MvdGemmArgs& a, int* tile, int* nstage, int* splitk) {
   const int M = a.M, N = a.N, nkt = a.Ktot / 64;
-  if (M > 4608 || a.ln_c1 || a.Ktot % 64 || N % 64) return false;
+  if (M > 4608 || a.Ktot % 64 || N % 64) return false;
   const bool conv = a.seg[0].mode == MVD_A_CONV3;
   if (conv && M >= 4096) return false;          // 64x64-level convolutions: the 128x160 / 256x320 kernels are as fast or faster
   int t = 0;
@@ -439,7 +548,7 @@ bool mvd_gemm_sm_plan(const MvdGemmArgs& a, int* tile, int* nstage, int* splitk)
   }
   const long tiles = (long)((M + kSmTiles[t].bm - 1) / kSmTiles[t].bm) * (N / kSmTiles[t].bn);
   int S = 1;
-  if (!a.geglu && tiles < 200) {
+  if (!a.geglu && !a.ln_c1 && tiles < 200) {
     S = (int)(256 / tiles);
     if (S > nkt / 12) S = nkt / 12;
     S = S < 1 ? 1 : (S > 16 ? 16 : S);

@@ -517,6 +517,9 @@ static bool launch_gn_slice(const bf16_t* x0, const bf16_t* x1, int c0, int c1, 
   return true;
 }
 
+// (A one-launch cooperative form for a single image -- rows dealt to co-resident workgroups, in-kernel rendezvous -- was
+//  built and measured in round 3: correct, but the rendezvous costs 12-15 us, more than the boundary + second launch of the
+//  two-kernel form it would replace; profiles/r03_probe_groupnorm_cooperative.log.)
 int mvd_launch_groupnorm(const bf16_t* x0, const bf16_t* x1, int c0, int c1, int batch, int hw, int groups, float eps,
                          const float* gamma, const float* beta, int silu, bf16_t* y, float* ws, hipStream_t s) {
   const int C = c0 + c1;

@@ -72,7 +72,7 @@ def _geglu_rows(w: torch.Tensor) -> torch.Tensor:
 
 # LayerNorm fold: only the 64x64 / 32x32 levels (C = 320 / 640 in SD-2.1) ever reach the fused kernel (it needs >= 200
 # tiles of 256x320, i.e. many rows); deeper levels keep ln_kernel + the plain GEMM and get no folded twin
-LN_FOLD_MAX_C = 640
+LN_FOLD_MAX_C = 1 << 30     # every level: the small-M kernels (batch 1) fold at C = 1280 too (the M = 32-images kernels stop at 640)
 
 
 def fold_layernorm(w: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, bias, device):

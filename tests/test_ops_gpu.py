@@ -425,3 +425,28 @@ def test_rows_beyond_m_are_never_written(ops):
         torch.cuda.synchronize()
         assert bool((buf[m:] == 7.0).all()), f"cfg {cfg} wrote rows >= M"
         close(buf[:m], a.float().cpu() @ w.float().cpu().T, what=f"cfg {cfg}")
+
+
+@pytest.mark.parametrize("m,c,nmul,geglu,offset", [(300, 320, 3, False, 0.3), (4096, 320, 1, False, 0.3), (1024, 640, 3, False, 4.0),
+                                                   (256, 1280, 3, False, 0.3), (64, 1280, 1, False, -2.0), (4096, 320, 8, True, 0.3),
+                                                   (1024, 640, 8, True, 0.3), (256, 1280, 8, True, 1.0), (64, 1280, 8, True, 0.3)])
+def test_sm_ln_linear(ops, m, c, nmul, geglu, offset):
+    """LayerNorm folded into the small-M GEMM (batch-1 shapes of every level): LayerNorm(x).W^T + b from the un-normalised rows."""
+    from mvd_amd.packing import fold_layernorm, _geglu_rows
+    n = nmul * c
+    x = (rnd(m, c, seed=1, scale=1.7, dtype=torch.float32) + offset).to(torch.bfloat16)
+    w = rnd(n, c, scale=1 / math.sqrt(c), seed=2, dtype=torch.float32)
+    gamma = 1 + 0.1 * rnd(c, seed=3, dtype=torch.float32)
+    beta = 0.1 * rnd(c, seed=4, dtype=torch.float32)
+    bias = rnd(n, seed=5, dtype=torch.float32)
+    ref = F.layer_norm(x.float(), (c,), gamma, beta, 1e-5) @ w.to(torch.bfloat16).float().T + bias
+    if geglu:
+        val, gate = ref.chunk(2, -1)
+        ref = val * F.gelu(gate)
+        w, bias = _geglu_rows(w), _geglu_rows(bias)
+    wf, cf = fold_layernorm(w, gamma, beta, bias, "cuda")
+    xc = x.cuda()
+    got = ops.ln_linear(xc, wf, cf, geglu=geglu)
+    close(got, ref, tol=2 ** -6, what=f"sm ln_linear {m}x{c}->{n} geglu={geglu}")
+    for _ in range(5):
+        assert torch.equal(got, ops.ln_linear(xc, wf, cf, geglu=geglu)), "fused LayerNorm GEMM is not bit-deterministic"

@@ -102,3 +102,19 @@ def test_vae_snapshot_that_fails_to_load_is_an_error_not_a_missing_vae(tmp_path)
     save_file({"bogus.weight": torch.zeros(3)}, str(d / "diffusion_pytorch_model.safetensors"))
     with pytest.raises(L.MvdError, match="failed to load"):
         _optional_components(str(tmp_path / "snap"), torch.float32)
+
+
+def test_small_m_kernels_use_no_scratch_memory():
+    """hipcc turns a runtime-indexed register array into scratch_load / scratch_store (which also count on vmcnt beside the
+    hand-counted LDS-DMA waits): the small-M GEMM must compile without a single scratch instruction and without spills."""
+    import tempfile
+    src = os.path.join(ROOT, "mvd_amd", "csrc", "gemm_sm.hip")
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "gemm_sm.s")
+        r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", src, "-o", out],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        asm = open(out).read()
+    assert "scratch_load" not in asm and "scratch_store" not in asm
+    import re
+    assert not re.search(r"\.vgpr_spill_count:\s*[1-9]", asm) and not re.search(r"\.private_segment_fixed_size:\s*[1-9]", asm)

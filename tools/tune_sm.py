@@ -118,7 +118,7 @@ def make(kind, p):
         res = rnd(M, N // 2 if p["geglu"] else N) if p.get("res") else None
         f32 = bool(p.get("f32"))
         out = torch.empty(M, N // 2 if p["geglu"] else N, device=dev, dtype=torch.float32 if f32 else torch.bfloat16)
-        ws = torch.empty(16 * M * N + 4096, device=dev, dtype=torch.float32)
+        ws = torch.empty(32 * M * N + 4096, device=dev, dtype=torch.float32)
 
         def run(cfg, sk):
             L.call("mvd_op_linear", C.c_void_p(a.data_ptr()), None, K, 0, C.c_void_p(w.data_ptr()), C.c_void_p(bias.data_ptr()), None, 0, 0,
@@ -135,7 +135,7 @@ def make(kind, p):
     res = rnd(M, cout) if p["res"] else None
     scx = rnd(M, sc) if sc else None
     out = torch.empty(M, cout, device=dev, dtype=torch.bfloat16)
-    ws = torch.empty(16 * M * cout + 4096, device=dev, dtype=torch.float32)
+    ws = torch.empty(32 * M * cout + 4096, device=dev, dtype=torch.float32)
     ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
 
     def run(cfg, sk):
@@ -159,12 +159,12 @@ for kind, name, p, count in unet_shapes(args.adapter):
         if N % bn or (geglu and (bn // 32) % 2):
             continue
         tiles = ((M + bm - 1) // bm) * (N // bn)
-        for sk in ([1] if geglu else [1, 2, 3, 4, 6, 8, 12, 16]):
-            if sk > 1 and (sk > nkt // 2 or tiles * sk > 640 or tiles >= 256):
+        for sk in ([1] if geglu else [1, 2, 3, 4, 6, 8, 12, 16, 24, 32]):
+            if sk > 1 and (sk > nkt // 2 or tiles * sk > 520 or tiles >= 256):
                 continue
             if tiles * sk > 4096 or (sk > 1 and tiles > 4096):
                 continue
-            for ns in ([3, 6] if args.quick else [2, 3, 4, 6, 8]):
+            for ns in ([3, 6] if args.quick else [2, 3, 4, 6]):
                 if ns > 2 and ns - 1 > math.ceil(nkt / sk) + 1:
                     continue
                 if ns * (bm + bn) * 128 > 160 * 1024:
