@@ -174,6 +174,11 @@ int mvd_op_conv3x3(const void* x, int batch, int in_h, int in_w, int cin, int st
  * by softmax_scale * log2(e) (the packed to_q / to_q_ref weight rows carry that factor, DESIGN.md "Weight slots"). */
 int mvd_op_attention(const void* q, const void* k, const void* v, void* o, int batch, int heads, int nq, int nk, int ldq,
                      int ldk, int ldv, int ldo, float scale, void* stream);
+/* Split-KV form (batch 1: too few (head, query block) pairs to fill the chip): the keys are cut into nsplit <= 8 ranges, one
+ * workgroup each, merged in the kernel by the last workgroup to arrive.  Prescaled queries only (the scale == 0 form). */
+int64_t mvd_op_attention_split_ws_bytes(int batch, int heads, int nq, int nsplit);
+int mvd_op_attention_split(const void* q, const void* k, const void* v, void* o, int batch, int heads, int nq, int nk, int ldq,
+                           int ldk, int ldv, int ldo, int nsplit, void* ws, void* stream);
 int mvd_op_groupnorm(const void* x0, const void* x1, int c0, int c1, int batch, int hw, int groups, float eps,
                      const float* gamma, const float* beta, int silu, void* y, float* ws, void* stream);
 int mvd_op_layernorm(const void* x, int rows, int c, float eps, const float* gamma, const float* beta, void* y,

@@ -78,8 +78,9 @@ MVD_DEVINL float pair_sum(float x) { float o; const float p = pair_other(x, o); 
 // round-robin to the 8 XCDs, so with the plain (query block fastest) order the 32 query blocks of one (batch, head) -- which
 // all stream the SAME K/V -- land on 8 different L2s and every L2 fetches that K/V for itself (PMC: 0.8 GB of L2 fills per
 // launch on average).  Here XCD x works through the (batch, head) pairs x, x + 8, ...: all query blocks of a pair share one L2.
-MVD_DEVINL void attn_block(const MvdAttnArgs& a, int& qb, int& head, int& bz) {
-  const int npair = a.heads * a.batch * a.nprob;
+MVD_DEVINL void attn_block(const MvdAttnArgs& a, int& qb, int& head, int& bz, int nsplit = 1, int* split = nullptr, int* pair_out = nullptr) {
+  // (split-KV: a (pair, key range) takes the place of the pair -- the query blocks that stream the same K/V RANGE share an L2)
+  const int npair = a.heads * a.batch * a.nprob * nsplit;
   const int nqb = gridDim.x / npair;
   const int lid = blockIdx.x;
   int pair;
@@ -89,16 +90,20 @@ MVD_DEVINL void attn_block(const MvdAttnArgs& a, int& qb, int& head, int& bz) {
   if ((npair & 7) == 0) { const int j = lid >> 3; qb = j % nqb; pair = (j / nqb) * 8 + (lid & 7); }
 #endif
   else { qb = lid % nqb; pair = lid / nqb; }
+  if (split) { *split = pair % nsplit; pair /= nsplit; }
   head = pair % a.heads;
   bz = pair / a.heads;
+  if (pair_out) *pair_out = pair;
 }
 
 // DMA: K/V tiles go global -> LDS by buffer-addressed LDS-DMA (no VGPR round trip, no ds_write, 16 registers fewer; the XOR
 // swizzles move to the source side; keys >= nk lie beyond num_records and arrive as zeros) instead of load + ds_write.
 // VSUM (with DMA): the softmax denominators are summed by 16x16x32 selector MFMAs (4 registers) instead of the "ones" V^T tile --
 // 12 accumulator registers less, which keeps the kernel at 128 registers: FOUR waves per SIMD.
-template <int NW, int NSUB, bool PRE, bool DMA = false, bool VSUM = false>
+// SPLIT (engine form only): split-KV, see MvdAttnArgs::nsplit.
+template <int NW, int NSUB, bool PRE, bool DMA = false, bool VSUM = false, bool SPLIT = false>
 __global__ __launch_bounds__(64 * NW, VSUM ? 4 : ((NW == 4 && NSUB == 2) ? 3 : 2)) void attn_kernel(const MvdAttnArgs a) {
+  static_assert(!SPLIT || (PRE && DMA && VSUM), "split-KV exists for the engine form");
   constexpr int NT = 64 * NW;
   constexpr int QB = 32 * NW;
   constexpr int KV_TILE = 32 * NSUB;
@@ -110,8 +115,10 @@ __global__ __launch_bounds__(64 * NW, VSUM ? 4 : ((NW == 4 && NSUB == 2) ? 3 : 2
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 31, lh = lane >> 5;
-  int qb_, head, bz;
-  attn_block(a, qb_, head, bz);
+  int qb_, head, bz, sp = 0, pair = 0;
+  const int nsplit = SPLIT ? a.nsplit : 1;
+  if constexpr (SPLIT) attn_block(a, qb_, head, bz, nsplit, &sp, &pair);
+  else attn_block(a, qb_, head, bz);
   const int pi = bz / a.batch;
   bz -= pi * a.batch;
   const MvdAttnProblem& P = a.p[pi];
@@ -232,9 +239,11 @@ __global__ __launch_bounds__(64 * NW, VSUM ? 4 : ((NW == 4 && NSUB == 2) ? 3 : 2
   const float c = a.scale * 1.4426950408889634f;  // scale * log2(e)   (unused when PRE)
   f32x16 negm = {};              // PRE: -m_run in every register (C operand that starts each score tile)
 
-  const int nkb = (nk + KV_TILE - 1) / KV_TILE;
-  if constexpr (DMA) { dma_tile(0, 0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-  load_tile(0);
+  const int nkb_all = (nk + KV_TILE - 1) / KV_TILE;
+  const int kb0 = SPLIT ? (sp * nkb_all) / nsplit : 0;                 // this workgroup's key tiles [kb0, nkb)
+  const int nkb = SPLIT ? ((sp + 1) * nkb_all) / nsplit : nkb_all;
+  if constexpr (DMA) { dma_tile(kb0, 0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  load_tile(kb0);
   store_tile(0);
   __syncthreads();
 
@@ -250,8 +259,8 @@ __global__ __launch_bounds__(64 * NW, VSUM ? 4 : ((NW == 4 && NSUB == 2) ? 3 : 2
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) k_base[ks] = k_off(lq, ks * 2 + lh);
 
-  for (int kb = 0; kb < nkb; ++kb) {
-    const int cur = kb & 1;
+  for (int kb = kb0; kb < nkb; ++kb) {
+    const int cur = (kb - kb0) & 1;
     const bool more = kb + 1 < nkb;
     if (more) { if constexpr (DMA) dma_tile(kb + 1, cur ^ 1); else load_tile(kb + 1); }   // (stage cur^1: last read before the previous barrier)
     const unsigned char* sk = smem + cur * TILE_BYTES;
@@ -298,10 +307,10 @@ __global__ __launch_bounds__(64 * NW, VSUM ? 4 : ((NW == 4 && NSUB == 2) ? 3 : 2
     if constexpr (PRE) {
       // s holds score - m_run (exp2 domain).  The first tile always sets the running max (m_run starts at 0, so a row
       // whose scores are all far below zero would otherwise underflow every P).
-      if (kb == 0 || !__all(mx <= RESCALE_LOG2)) {
+      if (kb == kb0 || !__all(mx <= RESCALE_LOG2)) {
         if constexpr (VSUM) mx = pair_max(mx);
-        const float delta = kb == 0 ? mx : fmaxf(mx, 0.f);     // m_new - m_run
-        if (kb != 0) {
+        const float delta = kb == kb0 ? mx : fmaxf(mx, 0.f);     // m_new - m_run
+        if (kb != kb0) {
           const float alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
           for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
@@ -399,6 +408,93 @@ __global__ __launch_bounds__(64 * NW, VSUM ? 4 : ((NW == 4 && NSUB == 2) ? 3 : 2
     inv = 1.0f / pair_sum(ol[0]);        // lanes 32..63 hold row 4 of the ones tile (= 0) in ol[0]
   }
 #endif
+  if constexpr (SPLIT) {
+    if (nsplit > 1) {
+      // ---- partial result of this key range -> workspace (write-through): [pair][query block][split][QB queries] rows of 64 bf16
+      // (normalised by THIS range's denominator) + (running max, denominator) per query; then one ticket per workgroup on the
+      // (pair, query block) counter -- the workgroup that draws the last one merges:
+      //   out = sum_s w_s O_s / sum_s w_s,  w_s = l_s 2^(m_s - max m)      (exp2 domain: the scores carry log2 e)
+      const int nqb = gridDim.x / (a.heads * a.batch * a.nprob * nsplit);
+      const size_t grp = (size_t)pair * nqb + qb_;                         // (pair, query block)
+      bf16_t* wo = reinterpret_cast<bf16_t*>(a.split_ws) + (grp * nsplit + sp) * (size_t)(QB * 64);
+      float2* wml = reinterpret_cast<float2*>(reinterpret_cast<bf16_t*>(a.split_ws) + (size_t)gridDim.x * (QB * 64)) + (grp * nsplit + sp) * QB;
+      __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(wo, 0, QB * 128, 0x00020000);
+      const int ql = wave * 32 + lq;                                       // query inside the block
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const u32x2 w0 = {pack2bf(o0[4 * g] * inv, o0[4 * g + 1] * inv), pack2bf(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv)};
+        const u32x2 w1 = {pack2bf(o1[4 * g] * inv, o1[4 * g + 1] * inv), pack2bf(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv)};
+        __builtin_amdgcn_raw_buffer_store_b64(w0, rs_o, ql * 128 + (8 * g + 4 * lh) * 2, 0, 16);          // aux 16 = sc1
+        __builtin_amdgcn_raw_buffer_store_b64(w1, rs_o, ql * 128 + (32 + 8 * g + 4 * lh) * 2, 0, 16);
+      }
+      if (lh == 0) {
+        typedef __attribute__((address_space(1))) unsigned long long gu64;
+        const float l = 1.0f / inv;
+        const unsigned long long pk = (unsigned long long)__builtin_bit_cast(unsigned, m_run) | ((unsigned long long)__builtin_bit_cast(unsigned, l) << 32);
+        __hip_atomic_store((gu64*)(wml + ql), pk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      int* flag = reinterpret_cast<int*>(smem);
+      if (tid == 0) {
+        typedef __attribute__((address_space(1))) unsigned int gu32;
+        *flag = (int)__hip_atomic_fetch_add((gu32*)(a.split_cnt + grp), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      if (*flag != nsplit - 1) return;
+      // ---- merge (the last workgroup to arrive): thread t -> query t >> 1, dims 32 (t & 1) .. + 31
+      const int mq = tid >> 1, mh = tid & 1;
+      const int mrow = qblk0 + mq;
+      const bf16_t* wo0 = reinterpret_cast<const bf16_t*>(a.split_ws) + grp * nsplit * (size_t)(QB * 64);
+      const float2* wml0 = reinterpret_cast<const float2*>(reinterpret_cast<const bf16_t*>(a.split_ws) + (size_t)gridDim.x * (QB * 64)) + grp * nsplit * QB;
+      __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(wo0), 0, nsplit * QB * 128, 0x00020000);
+      typedef __attribute__((address_space(1))) unsigned long long gu64c;
+      float mmax = -3.0e38f;
+      float ms[8], ls[8];
+#pragma unroll
+      for (int s2 = 0; s2 < 8; ++s2) {
+        ms[s2] = -3.0e38f; ls[s2] = 0.f;
+        if (s2 < nsplit) {
+          const unsigned long long pk = __hip_atomic_load((gu64c*)(wml0 + s2 * QB + mq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ms[s2] = __builtin_bit_cast(float, (unsigned)pk); ls[s2] = __builtin_bit_cast(float, (unsigned)(pk >> 32));
+          mmax = fmaxf(mmax, ms[s2]);
+        }
+      }
+      float accv[32];
+#pragma unroll
+      for (int j = 0; j < 32; ++j) accv[j] = 0.f;
+      float lt = 0.f;
+#pragma unroll
+      for (int s2 = 0; s2 < 8; ++s2) {
+        if (s2 < nsplit) {
+          const float wgt = ls[s2] * __builtin_amdgcn_exp2f(ms[s2] - mmax);
+          lt += wgt;
+#pragma unroll
+          for (int c4 = 0; c4 < 4; ++c4) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_i, (s2 * QB + mq) * 128 + mh * 64 + c4 * 16, 0, 16);   // sc1
+            const unsigned dw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              accv[c4 * 8 + 2 * e] = fmaf(wgt, bflo(dw[e]), accv[c4 * 8 + 2 * e]);
+              accv[c4 * 8 + 2 * e + 1] = fmaf(wgt, bfhi(dw[e]), accv[c4 * 8 + 2 * e + 1]);
+            }
+          }
+        }
+      }
+      if (mrow < nq) {
+        const float il = 1.0f / lt;
+        bf16_t* orow = op + (size_t)mrow * P.ldo + mh * 32;
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+          const u32x4 o = {pack2bf(accv[c4 * 8] * il, accv[c4 * 8 + 1] * il), pack2bf(accv[c4 * 8 + 2] * il, accv[c4 * 8 + 3] * il),
+                           pack2bf(accv[c4 * 8 + 4] * il, accv[c4 * 8 + 5] * il), pack2bf(accv[c4 * 8 + 6] * il, accv[c4 * 8 + 7] * il)};
+          *reinterpret_cast<u32x2*>(orow + c4 * 8) = u32x2{o.x, o.y};
+          *reinterpret_cast<u32x2*>(orow + c4 * 8 + 4) = u32x2{o.z, o.w};
+        }
+      }
+      return;
+    }
+  }
   if (qrow < nq) {
     bf16_t* orow = op + (size_t)qrow * P.ldo;
 #pragma unroll
@@ -869,14 +965,26 @@ __global__ __launch_bounds__(512, 2) void attn_pp_kernel(const MvdAttnArgs a) {
 #endif  // MVD_PROBE
 
 thread_local int g_last_attn[2] = {0, 0};
+static int g_attn_pipe_override = 0;
 
 template <int NW, int NSUB>
 int launch_nw(const MvdAttnArgs& a, int maxq, hipStream_t s) {
   const int qb = 32 * NW;
+  if (a.nsplit > 1) {   // split-KV: the engine form at 4 waves only (mvd_launch_attention has checked the arguments)
+    if constexpr (NW == 4 && NSUB == 2) {
+      dim3 grid(((maxq + qb - 1) / qb) * a.heads * a.batch * a.nprob * a.nsplit);
+      g_last_attn[0] = NW; g_last_attn[1] = (int)grid.x;
+      hipLaunchKernelGGL((attn_kernel<4, 2, true, true, true, true>), grid, dim3(256), 4 * 32 * 2 * 128, s, a);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) { mvd_set_error("attention (split-KV) launch: %s", hipGetErrorString(e)); return -3; }
+      return 0;
+    } else { mvd_set_error("attention: split-KV needs the 4-wave form"); return -1; }
+  }
   dim3 grid(((maxq + qb - 1) / qb) * a.heads * a.batch * a.nprob);      // 1-D: attn_block() decodes it
   // (the software-pipelined kernel is an experiment switch: at two waves per SIMD it measured 13 % SLOWER than the
   //  three-wave kernel above -- inter-wave overlap beats the intra-wave pipeline hipcc schedules; MVD_ATTN_PIPE=1)
-  static const int pipe = MVD_ENV_INT("MVD_ATTN_PIPE", 0);
+  static const int pipe_env = MVD_ENV_INT("MVD_ATTN_PIPE", 0);
+  const int pipe = pipe_env || g_attn_pipe_override;
   g_last_attn[0] = NW; g_last_attn[1] = (int)grid.x;
   if (a.prescaled && NW == 4 && NSUB == 2 && pipe) hipLaunchKernelGGL((attn_pipe_kernel<4>), grid, dim3(256), 0, s, a);
   else if (a.prescaled) {
@@ -902,7 +1010,12 @@ int launch_nw(const MvdAttnArgs& a, int maxq, hipStream_t s) {
 int mvd_attention_pick_nw(const MvdAttnArgs& a);
 static int g_attn_nw_override = -1;
 // measurement hook (tools/, bench.py --attn-nw): log2 of the waves per workgroup for every later launch, -1 = heuristic
-extern "C" int mvd_debug_set_attention_nw(int nw_log2) { g_attn_nw_override = nw_log2; return 0; }
+// (nw_log2 + 16: additionally the software-pipelined 4-wave variant)
+extern "C" int mvd_debug_set_attention_nw(int nw_log2) {
+  g_attn_pipe_override = nw_log2 >= 16;
+  g_attn_nw_override = nw_log2 >= 16 ? nw_log2 - 16 : nw_log2;
+  return 0;
+}
 
 // out[2] = {waves per workgroup, workgroups} of the calling thread's last attention launch
 extern "C" int mvd_debug_last_attention_plan(int* out) {
@@ -947,6 +1060,12 @@ int mvd_launch_attention(const MvdAttnArgs& a, hipStream_t s) {
     }
   }
 #endif
+  if (a.nsplit > 1) {
+    if (!a.prescaled || a.nsplit > 8 || !a.split_ws || !a.split_cnt || mink < 64 * a.nsplit) { mvd_set_error("attention: bad split-KV request (nsplit=%d, fewest keys %d)", a.nsplit, mink); return -1; }
+    for (int i = 0; i < a.nprob; ++i)
+      if ((size_t)a.p[i].nk * (a.p[i].ldk > a.p[i].ldv ? a.p[i].ldk : a.p[i].ldv) * 2 >= ((size_t)1 << 31)) { mvd_set_error("attention: split-KV operand too large for buffer addressing"); return -1; }
+    return launch_nw<4, 2>(a, maxq, s);
+  }
   switch (mvd_attention_pick_nw(a)) {
     case 3: return launch_nw<8, 2>(a, maxq, s);
     case 2: return big ? launch_nw<4, 4>(a, maxq, s) : launch_nw<4, 2>(a, maxq, s);
@@ -954,6 +1073,30 @@ int mvd_launch_attention(const MvdAttnArgs& a, hipStream_t s) {
     default: return launch_nw<1, 2>(a, maxq, s);
   }
 }
+
+// Split-KV (batch 1): with about one wave per SIMD the kernel runs at a fraction of its rate (one wave's softmax and MFMA
+// phases do not overlap); cutting the keys over several workgroups restores some occupancy.  All problems of a launch get
+// the same split.
+int mvd_attention_pick_split(const MvdAttnArgs& a) {
+  if (!a.prescaled) return 1;
+  int maxq = 0, mink = 1 << 30;
+  for (int i = 0; i < a.nprob; ++i) { maxq = a.p[i].nq > maxq ? a.p[i].nq : maxq; mink = a.p[i].nk < mink ? a.p[i].nk : mink; }
+  const long waves = (long)a.heads * a.batch * a.nprob * ((maxq + 127) / 128) * 4;
+  // measured (profiles/r03_probe_attention_batch1.log): worth it only for long key sequences on a nearly empty chip --
+  // 4096 keys x 5 heads 51 -> 38 us at 3 ranges (4: 43, 8: 56: the partials and the merge cost more than the occupancy
+  // gains); 1024 keys x 10 heads 13.8 us unsplit against 16+ split
+  if (maxq < 128 || mink < 2048 || waves >= 2048) return 1;
+  return waves < 1024 ? 3 : 2;
+}
+static long attn_split_groups(const MvdAttnArgs& a) {
+  int maxq = 0;
+  for (int i = 0; i < a.nprob; ++i) maxq = a.p[i].nq > maxq ? a.p[i].nq : maxq;
+  return (long)a.heads * a.batch * a.nprob * ((maxq + 127) / 128);
+}
+size_t mvd_attention_split_ws_bytes(const MvdAttnArgs& a, int nsplit) {
+  return (size_t)attn_split_groups(a) * nsplit * 128 * (128 + 8);     // per (group, split): 128 queries x (64 bf16 + float2)
+}
+int mvd_attention_split_counters(const MvdAttnArgs& a) { return (int)attn_split_groups(a); }
 
 // log2 of the waves per workgroup: enough workgroups to fill 256 CUs; 4-wave workgroups (128 queries) fit
 // three per CU at ~165 VGPRs, the 8-wave shape only one
@@ -965,6 +1108,9 @@ int mvd_attention_pick_nw(const MvdAttnArgs& a) {
   if (force >= 0) return force;
   if (g_attn_nw_override >= 0) return g_attn_nw_override;
   if (maxq >= 128 && heads_total * ((maxq + 127) / 128) >= 512) return 2;
+  // few workgroups (batch 1): the 4-wave engine form (LDS-DMA staging, denominators on the matrix pipe) still wins over the
+  // register-staged 1- and 2-wave forms -- 4096^2 x 5 heads: 51 us against 83 / 93 (profiles/r03_probe_attention_batch1.log)
+  if (maxq >= 128 && a.prescaled) return 2;
   if (maxq >= 64) return 1;
   return 0;
 }

@@ -21,7 +21,7 @@
 int mvd_launch_silu_to_bf16(const float* x, int64_t n, bf16_t* y, hipStream_t s);
 
 // measurement / bisection switches (bench.py --debug-flags, tools/): bit 0 = no LayerNorm fold through the small-M kernels,
-// bit 1 = small-M kernels never split K, bit 2 = small-M kernels off
+// bit 1 = small-M kernels never split K, bit 2 = small-M kernels off, bit 3 = no split-KV attention
 static int g_debug_flags = 0;
 extern "C" int mvd_debug_set_flags(int flags) { g_debug_flags = flags; return 0; }
 
@@ -280,7 +280,19 @@ struct Ctx {
     return profiled(17, 0.0, 2.0 * rows * (double)c * 2, [&] { return mvd_launch_layernorm(x, rows, c, 1e-5f, g, b, y, s); });
   }
   int attention(MvdAttnArgs& a) {
-    if (err) return err; if (dry) return 0;
+    if (err) return err;
+    // batch 1: split the keys over several workgroups (partials + counters from the scoped workspace / the call's counter block)
+    const size_t mark = e->tmp.off;
+    const int ns = (g_debug_flags & 8) ? 1 : mvd_attention_pick_split(a);
+    if (ns > 1) {
+      a.nsplit = ns;
+      a.split_ws = e->tmp.alloc(mvd_attention_split_ws_bytes(a, ns));
+      a.split_cnt = e->cnt_base + e->cnt_used;
+      e->cnt_used += mvd_attention_split_counters(a);
+      if (!dry && e->cnt_used > e->cnt_cap) { mvd_set_error("forward: tile counters exhausted (%d > %d)", e->cnt_used, e->cnt_cap); return err = -15; }
+    }
+    e->tmp.off = mark;
+    if (dry) return 0;
     double fl = 0;
     for (int i = 0; i < a.nprob; ++i) fl += 4.0 * a.batch * a.heads * (double)a.p[i].nq * a.p[i].nk * 64;
     e->prof_M = a.p[0].nq; e->prof_N = a.p[0].nk; e->prof_K = a.heads; e->prof_tag = 1000 + a.nprob;
@@ -1206,6 +1218,28 @@ int mvd_op_attention(const void* q, const void* k, const void* v, void* o, int b
   a.prescaled = scale == 0.f;   // q already carries softmax_scale * log2(e)
   a.p[0] = {(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, ldq, ldk, ldv, ldo,
             (int64_t)nq * ldq, (int64_t)nk * ldk, (int64_t)nk * ldv, (int64_t)nq * ldo, nq, nk};
+  return mvd_launch_attention(a, (hipStream_t)stream);
+}
+
+// split-KV form of mvd_op_attention (prescaled queries only: scale == 0): ws = mvd_op_attention_split_ws_bytes(...) bytes
+// (partials + the arrival counters, which the call zeroes)
+int64_t mvd_op_attention_split_ws_bytes(int batch, int heads, int nq, int nsplit) {
+  MvdAttnArgs a; memset(&a, 0, sizeof(a));
+  a.nprob = 1; a.batch = batch; a.heads = heads; a.p[0].nq = nq;
+  return (int64_t)mvd_attention_split_ws_bytes(a, nsplit) + (int64_t)mvd_attention_split_counters(a) * 4 + 256;
+}
+int mvd_op_attention_split(const void* q, const void* k, const void* v, void* o, int batch, int heads, int nq, int nk, int ldq,
+                           int ldk, int ldv, int ldo, int nsplit, void* ws, void* stream) {
+  MvdAttnArgs a; memset(&a, 0, sizeof(a));
+  a.nprob = 1; a.batch = batch; a.heads = heads; a.scale = 0.f; a.prescaled = 1;
+  a.p[0] = {(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, ldq, ldk, ldv, ldo,
+            (int64_t)nq * ldq, (int64_t)nk * ldk, (int64_t)nk * ldv, (int64_t)nq * ldo, nq, nk};
+  if (nsplit > 1) {
+    if (!ws) { mvd_set_error("op_attention_split: null workspace"); return -1; }
+    const size_t pb = (mvd_attention_split_ws_bytes(a, nsplit) + 255) & ~size_t(255);
+    a.nsplit = nsplit; a.split_ws = ws; a.split_cnt = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(ws) + pb);
+    if (hipMemsetAsync(a.split_cnt, 0, (size_t)mvd_attention_split_counters(a) * 4, (hipStream_t)stream) != hipSuccess) { mvd_set_error("op_attention_split: hipMemsetAsync failed"); return -3; }
+  }
   return mvd_launch_attention(a, (hipStream_t)stream);
 }
 

@@ -95,7 +95,17 @@ struct MvdAttnArgs {
   float scale;                    // softmax scale (1/sqrt(64))
   int prescaled;                  // 1: q is already multiplied by scale*log2(e) (host-folded into to_q); scale unused
   int dbg;                        // probe builds only (-DMVD_PROBE, env MVD_ATTN_DBG): ablation bits of the ping-pong kernel
+  // split-KV (batch 1: too few (head, query block) pairs to fill the chip): the keys of every problem are cut into `nsplit`
+  // ranges, one workgroup each; partial results (normalised O as bf16 + (running max, denominator) per query) go to
+  // `split_ws` and the workgroup that arrives last on the (problem, batch, head, query block) counter merges them.
+  int nsplit;                     // <= 1: off
+  void* split_ws;                 // mvd_attention_split_ws_bytes(a) bytes
+  unsigned int* split_cnt;        // mvd_attention_split_counters(a) ZEROED counters
 };
+// split the engine's heuristic gives this launch (1 = none) and what it then needs
+int mvd_attention_pick_split(const MvdAttnArgs& a);
+size_t mvd_attention_split_ws_bytes(const MvdAttnArgs& a, int nsplit);
+int mvd_attention_split_counters(const MvdAttnArgs& a);
 int mvd_launch_attention(const MvdAttnArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- normalisation

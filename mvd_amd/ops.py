@@ -92,6 +92,18 @@ def attention(q, k, v, heads, scale=0.125):
     return out
 
 
+def attention_split(q, k, v, heads, nsplit):
+    """Split-KV attention (engine form: q carries softmax_scale * log2 e); the keys are cut into ``nsplit`` ranges."""
+    _bf16(q, k, v)
+    B, nq, _ = q.shape
+    nk = k.shape[1]
+    out = torch.empty(B, nq, heads * 64, device=q.device, dtype=torch.bfloat16)
+    ws = torch.empty(int(L.lib().mvd_op_attention_split_ws_bytes(B, heads, nq, nsplit)), device=q.device, dtype=torch.uint8)
+    L.call("mvd_op_attention_split", C.c_void_p(q.data_ptr()), C.c_void_p(k.data_ptr()), C.c_void_p(v.data_ptr()), _p(out),
+           B, heads, nq, nk, q.stride(1), k.stride(1), v.stride(1), heads * 64, nsplit, _p(ws), _s())
+    return out
+
+
 def groupnorm(x, gamma, beta, groups=32, eps=1e-5, silu=False, x2=None):
     """x: (B,HW,C0) bf16 [, x2: (B,HW,C1) concatenated on channels] -> (B,HW,C0+C1)"""
     _bf16(x, x2)

@@ -450,3 +450,30 @@ def test_sm_ln_linear(ops, m, c, nmul, geglu, offset):
     close(got, ref, tol=2 ** -6, what=f"sm ln_linear {m}x{c}->{n} geglu={geglu}")
     for _ in range(5):
         assert torch.equal(got, ops.ln_linear(xc, wf, cf, geglu=geglu)), "fused LayerNorm GEMM is not bit-deterministic"
+
+
+@pytest.mark.parametrize("B,heads,nq,nk,nsplit,shift", [
+    (1, 5, 4096, 4096, 4, 0.0),        # the 64x64-level self-attention of a batch-1 forward
+    (1, 10, 1024, 1024, 4, 0.0), (1, 10, 1024, 1024, 2, 0.0),
+    (1, 2, 200, 1000, 3, 0.0),         # ragged query block and a ragged last key tile, 16 tiles over 3 ranges
+    (2, 3, 384, 2048, 8, 0.0),
+    (1, 2, 256, 640, 2, -40.0),        # every score far below zero: each range's first tile sets its running max
+    (1, 2, 256, 640, 2, 25.0),
+])
+def test_attention_split_kv(ops, B, heads, nq, nk, nsplit, shift):
+    """Split-KV (batch 1): per-range partials merged by the last workgroup; same tolerance as the unsplit engine form, and the
+    merge is bit-deterministic (fixed range order) whoever arrives last."""
+    from mvd_amd.packing import QSCALE
+    C = heads * 64
+    q, k, v = rnd(B, nq, C, seed=1), rnd(B, nk, C, seed=2), rnd(B, nk, C, seed=3)
+    if shift:
+        k = (k.float() + 1.0).to(torch.bfloat16)
+        q = (q.float() + shift * 8.0 / 64.0).to(torch.bfloat16)
+    qs = (q.float() * QSCALE).to(torch.bfloat16)
+    sp = lambda t, n: t.float().view(B, n, heads, 64).transpose(1, 2)  # noqa: E731
+    want = F.scaled_dot_product_attention(sp(qs, nq) * 0.6931471805599453, sp(k, nk), sp(v, nk), scale=1.0)
+    qc, kc, vc = qs.cuda(), k.cuda(), v.cuda()
+    got = ops.attention_split(qc, kc, vc, heads, nsplit)
+    close(got, want.transpose(1, 2).reshape(B, nq, C), tol=2 ** -6, what=f"split-KV attention {B}x{heads}x{nq}x{nk} / {nsplit}")
+    for _ in range(4):
+        assert torch.equal(got, ops.attention_split(qc, kc, vc, heads, nsplit)), "split-KV merge is not bit-deterministic"
