@@ -117,7 +117,7 @@ def make_batch(pairs: int, rank: int, device, lat_hw: int = 64):
     return {k: v.to(device).contiguous() for k, v in dict(sample=sample, text=text, lat=lat, src=src, tgt=tgt, t=t).items()}
 
 
-def cpu_baseline(timed_runs: int = 3, warmup_runs: int = 1):
+def cpu_baseline(timed_runs: int = 3, warmup_runs: int = 1, latent: int = 64):
     """The oracle (CPU fp32 restatement, oracle/mvd.py) timed on this box's host cores: configs[2] (B=1, adapter + camera
     on, cold forward; ~13 s per forward on the GPU box's 128 usable threads).  BASELINE.md section 3 protocol: 1 warm-up
     forward, then ``timed_runs`` timed ones, MEDIAN reported (~55 s of CPU work in all).  The only place bench.py
@@ -131,7 +131,7 @@ def cpu_baseline(timed_runs: int = 3, warmup_runs: int = 1):
     cores = torch.get_num_threads()
     cfg = OU.UNetConfig.sd21()
     params = OM.init_mvd_params(cfg, 0, share_encoder=True)
-    inp = make_inputs(cfg, 1, 64, 77, 0, 1024)
+    inp = make_inputs(cfg, 1, latent, 77, 0, 1024)
     times = []
     with torch.no_grad():
         for i in range(warmup_runs + timed_runs):
@@ -142,7 +142,8 @@ def cpu_baseline(timed_runs: int = 3, warmup_runs: int = 1):
                 times.append(time.perf_counter() - t0)
     med = statistics.median(times)
     return {"value": 1.0 / med, "unit": "forward-passes/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/mvd.py, configs[2] (B=1, 64x64 latent, adapter+camera on, cold forward = {(F_ADAPTER_MAIN + F_ENCODER) / 1e9:.0f} GFLOP), "
+            "sample": f"oracle/mvd.py, configs[2] (B=1, {latent}x{latent} latent, adapter+camera on, cold forward = "
+                      f"{(unet_flops(latent, latent, adapter=True) + unet_flops(latent, latent)) / 1e9:.0f} GFLOP), "
                       f"{warmup_runs} warm-up + {timed_runs} timed forwards (median; min {min(times):.2f} s, max {max(times):.2f} s), "
                       f"torch fp32 on {cores} host threads (os.cpu_count()={os.cpu_count()}), {med:.2f} s/forward"}
 
@@ -204,6 +205,79 @@ def output_check(model, batch, kw, step):
     return res
 
 
+def e2e_workload(args, dev):
+    """BASELINE's metric is the UNet forward; the one number the reference itself measures is seconds per generated image
+    (/root/reference/val.py:331-347).  This workload times what infer.py:111-122 runs for ONE image: VAE encode of the source
+    image -> N-step denoising loop (B = 1, guidance 1.0, camera + image conditioning) -> VAE decode, through
+    ``MVDPipeline.__call__``, synthetic weights of the SD-2.1 shapes.  ``--cached`` = cache_reference (Q5)."""
+    import statistics
+    from mvd_amd.config import UNetConfig
+    from mvd_amd.mvd_unet import MultiViewUNet
+    from mvd_amd.pipeline import MVDPipeline
+    from mvd_amd.scheduler import DDPMScheduler, ShiftSNRScheduler
+    from mvd_amd.utils import look_at
+    from mvd_amd.vae import AutoencoderKLHIP
+    L_ = args.latent
+    model = MultiViewUNet(None, unet_config=UNetConfig.sd21(), init="empty", img_ref_scale=0.25, cam_modulation_strength=1.0,
+                          cache_reference=args.cached, dedup_encoder_weights=False).to(dev)
+    model.eval()
+    fill_synthetic_weights(model, 0)
+    model._sync_engine()
+    torch.manual_seed(1)
+    vae = AutoencoderKLHIP().to(dev)          # SD-2.1 VAE topology (83.65 M parameters), torch default init
+    sched = ShiftSNRScheduler.from_scheduler(noise_scheduler=DDPMScheduler(), shift_mode="interpolated", shift_scale=6.0,
+                                             scheduler_class=DDPMScheduler)
+    pipe = MVDPipeline(model, sched, vae=vae)
+    g = torch.Generator().manual_seed(7)
+    embeds = torch.randn(1, 77, 1024, generator=g).to(dev)
+    img = (torch.rand(1, 3, 8 * L_, 8 * L_, generator=g) * 2 - 1).to(dev)
+    src, tgt = look_at(0.0)[None].to(dev), look_at(90.0)[None].to(dev)
+    nsteps = args.e2e_steps
+
+    def one_image():
+        return pipe(prompt_embeds=embeds, height=8 * L_, width=8 * L_, num_inference_steps=nsteps, guidance_scale=1.0,
+                    source_camera=src, target_camera=tgt, source_images=img, output_type="pt")["images"]
+
+    def timed(fn, n):
+        ts = []
+        for _ in range(n):
+            torch.cuda.synchronize(); t0 = time.perf_counter(); out = fn(); torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return statistics.median(ts), out
+
+    for _ in range(max(1, args.warmup)):
+        out = one_image()
+    assert torch.isfinite(out).all() and out.shape == (1, 3, 8 * L_, 8 * L_)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_image()
+    torch.cuda.synchronize()
+    per_image = (time.perf_counter() - t0) / args.steps
+    t_enc, dist = timed(lambda: vae.encode(img).latent_dist.sample(), 5)
+    lat = dist * vae.config.scaling_factor
+    t_dec, _ = timed(lambda: vae.decode(lat / vae.config.scaling_factor).sample, 5)
+    f_main, f_base = unet_flops(L_, L_, adapter=True), unet_flops(L_, L_)
+    fl = nsteps * f_main + (1 if args.cached else nsteps) * f_base
+    cpu = None if args.no_cpu_baseline else cpu_baseline(1, 0, L_)
+    line = {"metric": "images/sec end to end (VAE encode + denoising loop + VAE decode), 1 GPU", "value": round(1.0 / per_image, 4),
+            "unit": "images/s", "seconds_per_image": round(per_image, 4), "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(per_image * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": f"e2e: one image as infer.py:111-122 runs it (B=1, guidance 1.0, camera + image conditioning, "
+                                   f"{'cache_reference (Q5)' if args.cached else 'reference encoder re-run every step'})",
+                       "image": f"{8 * L_}x{8 * L_}", "latent": f"{L_}x{L_}x4", "denoising_steps": nsteps, "text_tokens": 77,
+                       "weights": "synthetic (UNet: seeded variance-preserving; VAE: torch default init), SD-2.1 shapes"},
+            "phases_ms": {"vae_encode": round(t_enc * 1e3, 2), "vae_decode": round(t_dec * 1e3, 2),
+                          "loop_and_glue": round((per_image - t_enc - t_dec) * 1e3, 2),
+                          "per_denoising_step": round((per_image - t_enc - t_dec) / nsteps * 1e3, 3)},
+            "shares": {"vae": round((t_enc + t_dec) / per_image, 3), "loop": round(1 - (t_enc + t_dec) / per_image, 3)},
+            "unet_tflops_in_loop": round(fl / max(per_image - t_enc - t_dec, 1e-9) / 1e12, 1),
+            "cpu_baseline": cpu, "kernel_src_sha": kernel_source_sha()}
+    print(json.dumps(line), flush=True)
+    return 0
+
+
 def launch_dry_run(args, D):
     """The N > 1 control flow of main() with the GPU work left out (CPU test of the self-launching entry): gloo process
     group from the launcher's environment, a weight-arena broadcast through the product's own helper, the barriers and the
@@ -235,7 +309,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=list(WORKLOADS), default="cfg4")
+    ap.add_argument("--workload", choices=list(WORKLOADS) + ["e2e"], default="cfg4")
+    ap.add_argument("--e2e-steps", type=int, default=20, help="--workload e2e: denoising steps per image (infer.py's default)")
     ap.add_argument("--pairs", type=int, default=0, help="override pairs per GPU")
     ap.add_argument("--cached", action="store_true", help="reuse the step-invariant reference K/V (Q5) instead of re-running the encoder")
     ap.add_argument("--graph", action="store_true", help="replay each forward as one hipGraphLaunch (mvd_engine_set_graph); pays at batch 1 only")
@@ -283,6 +358,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
+    if args.workload == "e2e":
+        if world != 1:
+            raise SystemExit("--workload e2e is a one-GPU workload")
+        return e2e_workload(args, dev)
     from mvd_amd.config import UNetConfig
     from mvd_amd.mvd_unet import MultiViewUNet
     pairs, use_cam, use_img, desc = WORKLOADS[args.workload]

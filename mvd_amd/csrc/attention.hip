@@ -507,6 +507,7 @@ __global__ __launch_bounds__(64 * NW, VSUM ? 4 : ((NW == 4 && NSUB == 2) ? 3 : 2
   }
 }
 
+#ifdef MVD_PROBE   // measurement-only kernels from here to the matching #endif (tools/build_variant.py <tag> -DMVD_PROBE)
 // ------------------------------------------------------------------------------------------------------------------
 // Software-pipelined variant (prescaled Q, 64-key tiles, 4 waves x 32 queries, two waves per SIMD / 256 registers):
 // the S^T = K.Q^T MFMAs of tile t+1 are issued UNDER the softmax of tile t (their accumulator is a second register
@@ -732,7 +733,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_pipe_kernel(const MvdAttnArgs
   }
 }
 
-#ifdef MVD_PROBE
 // ------------------------------------------------------------------------------------------------------------------
 // "Ping-pong" attention (prescaled Q, 64-key tiles): 8 waves x 32 queries per workgroup, one workgroup per CU, the two
 // waves of every SIMD (waves w and w + 4) ONE PHASE APART, as in gemm_pp.hip.  A wave's key tile t is two phases, each
@@ -983,11 +983,17 @@ int launch_nw(const MvdAttnArgs& a, int maxq, hipStream_t s) {
   dim3 grid(((maxq + qb - 1) / qb) * a.heads * a.batch * a.nprob);      // 1-D: attn_block() decodes it
   // (the software-pipelined kernel is an experiment switch: at two waves per SIMD it measured 13 % SLOWER than the
   //  three-wave kernel above -- inter-wave overlap beats the intra-wave pipeline hipcc schedules; MVD_ATTN_PIPE=1)
-  static const int pipe_env = MVD_ENV_INT("MVD_ATTN_PIPE", 0);
-  const int pipe = pipe_env || g_attn_pipe_override;
   g_last_attn[0] = NW; g_last_attn[1] = (int)grid.x;
-  if (a.prescaled && NW == 4 && NSUB == 2 && pipe) hipLaunchKernelGGL((attn_pipe_kernel<4>), grid, dim3(256), 0, s, a);
-  else if (a.prescaled) {
+#ifdef MVD_PROBE
+  static const int pipe_env = MVD_ENV_INT("MVD_ATTN_PIPE", 0);
+  if (a.prescaled && NW == 4 && NSUB == 2 && (pipe_env || g_attn_pipe_override)) {
+    hipLaunchKernelGGL((attn_pipe_kernel<4>), grid, dim3(256), 0, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { mvd_set_error("attention launch: %s", hipGetErrorString(e)); return -3; }
+    return 0;
+  }
+#endif
+  if (a.prescaled) {
 #ifdef MVD_ATTN_NO_DMA          // (A/B builds)
     constexpr bool dma = false;
 #else
@@ -1039,9 +1045,9 @@ int mvd_launch_attention(const MvdAttnArgs& a, hipStream_t s) {
   // 128-key tiles are an experiment switch only (env MVD_ATTN_KV128=1): at 197 VGPRs / 64 KB LDS they run two
   // waves per SIMD instead of three and measured 3-4 % SLOWER than 64-key tiles on every UNet shape
   // (profiles/r01_probe_attention_kv128.log)
+#ifdef MVD_PROBE
   static const int kv128 = MVD_ENV_INT("MVD_ATTN_KV128", 0);
   const bool big = kv128 != 0 && mink >= 256 && !a.prescaled;
-#ifdef MVD_PROBE
   // EXPERIMENT (probe builds, MVD_ATTN_PP=1): the ping-pong kernel -- measured 5-15 % slower than the free-running kernels
   // (profiles/r02_probe_attention_pingpong.log: its vector phase is twice as long as its matrix phase)
   static const int use_pp = MVD_ENV_INT("MVD_ATTN_PP", 0);
@@ -1067,8 +1073,13 @@ int mvd_launch_attention(const MvdAttnArgs& a, hipStream_t s) {
     return launch_nw<4, 2>(a, maxq, s);
   }
   switch (mvd_attention_pick_nw(a)) {
+#ifdef MVD_PROBE   // (8-wave workgroups and 128-key tiles: measured slower everywhere, probe builds only)
     case 3: return launch_nw<8, 2>(a, maxq, s);
     case 2: return big ? launch_nw<4, 4>(a, maxq, s) : launch_nw<4, 2>(a, maxq, s);
+#else
+    case 3:
+    case 2: return launch_nw<4, 2>(a, maxq, s);
+#endif
     case 1: return launch_nw<2, 2>(a, maxq, s);
     default: return launch_nw<1, 2>(a, maxq, s);
   }

@@ -674,9 +674,17 @@ int mvd_launch_gemm(const MvdGemmArgs& a, hipStream_t s, int force_cfg) {
   }
   if (cfg < 0 || cfg >= kNumCfgs || a.N % kCfgs[cfg].bn || (a.geglu && !kCfgs[cfg].tn_even)) { mvd_set_error("gemm: no tile config for N=%d geglu=%d cfg=%d", a.N, a.geglu, cfg); return -1; }
   g_mvd_last_gemm.cfg = cfg; g_mvd_last_gemm.splitk = a.splitk > 1 ? a.splitk : 1;
+#ifndef MVD_PROBE
+  // tile configs the heuristic never picks (256x160, 256x128, 128x320) and the lock-step forms of 6 / 7 as a forced choice
+  // exist in probe builds only (tools/build_variant.py <tag> -DMVD_PROBE)
+  if (cfg == 0 || cfg == 1 || cfg == 8 || force_cfg == 16 || force_cfg == 17) { mvd_set_error("gemm: tile config %d exists in probe builds only", force_cfg >= 0 ? force_cfg : cfg); return -1; }
+#endif
   switch (cfg) {
+#ifdef MVD_PROBE
     case 0: return launch_cfg<C0>(a, s, glds);
     case 1: return launch_cfg<C1>(a, s, glds);
+    case 8: return launch_cfg<C8>(a, s, true);
+#endif
     case 2: return launch_cfg<C2>(a, s, glds);
     case 3: return launch_cfg<C3>(a, s, glds);
     case 4: return launch_cfg<C4>(a, s, glds);
@@ -690,7 +698,6 @@ int mvd_launch_gemm(const MvdGemmArgs& a, hipStream_t s, int force_cfg) {
       if (use_ring && !a.out_f32 && !a.dbg) return mvd_launch_gemm_ring(a, s);
 #endif
       return launch_cfg<C7>(a, s, true);
-    case 8: return launch_cfg<C8>(a, s, true);
     default: return launch_cfg<C5>(a, s, glds);
   }
 }

@@ -213,3 +213,48 @@ def test_tiny_denoise_loop_parity(tiny):
     model.cache_reference = False
     assert torch.isfinite(got).all()
     assert rel_l2(got, want) <= 4e-2, rel_l2(got, want)      # 4 chained bf16 UNet evaluations
+
+
+def test_sd21_full_size_parity_768():
+    """The reference's own default: 768 x 768 images = 96 x 96 latents (infer.py:187, config/train_config.yaml sample_size 96), full
+    SD-2.1 shapes, B = 1, camera FiLM + cross-view adapter, cold forward: 9216 tokens at the first level (the split-KV attention,
+    the small-M GEMMs at M = 9216 / 2304 / 576 / 144) under the checker.  The oracle needs ~40 s of CPU."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from tests.parity_util import run_tiny_parity
+    stats = run_tiny_parity(batch=1, verbose=True, cfg_name="sd21", hw=96, text_len=77)
+    assert stats["finite"]
+    assert stats["rel_l2"] <= TOL_L2, stats
+    assert stats["max_rel"] <= TOL_MAX, stats
+
+
+def test_sd21_full_size_denoise_loop_cfg():
+    """A 4-step classifier-free-guidance loop of ``MVDDenoiser`` (pipeline.py:140-166) at full SD-2.1 size: B = 1 object (2 latents
+    per forward under CFG: the Q4 re-chunking of the reference tokens), camera + image conditioning, the per-step Fourier
+    projection pinned, the same ancestral noise draws as ``oracle/scheduler.denoise_loop``.  Quantifies the error growth over
+    chained bf16 forwards (one forward: rel-L2 ~1e-2): stated tolerance rel-L2 <= 5e-2 on the final latents."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mvd_amd.pipeline import MVDDenoiser
+    from mvd_amd.scheduler import DDPMScheduler, ShiftSNRScheduler
+    from oracle import scheduler as OS
+    from tests.parity_util import make_inputs, rel_l2, shared_pair
+    cfg, params, model = shared_pair("sd21")
+    inp = make_inputs(cfg, 1, 64, 77, seed=41, cam_dim=1024)
+    sched = ShiftSNRScheduler.from_scheduler(DDPMScheduler(), "interpolated", shift_scale=6.0, scheduler_class=DDPMScheduler)
+    steps, gs = 4, 3.0
+    g = torch.Generator().manual_seed(6)
+    noises = [torch.randn(1, 4, 64, 64, generator=g) for _ in range(steps)]
+    neg = torch.randn(1, 77, cfg.cross_attention_dim, generator=g)
+    lat0 = torch.randn(1, 4, 64, 64, generator=g)
+    want = OS.denoise_loop(params, cfg, sched.betas, inp["text"], neg, lat0, inp["src"], inp["tgt"], inp["lat"], steps, gs, noises,
+                           [inp["proj"]] * steps, img_ref_scale=0.3, cam_modulation_strength=0.2)
+    model.fourier_projection = inp["proj"]
+    den = MVDDenoiser(model, sched)
+    got = den(inp["text"].cuda(), steps, gs, negative_prompt_embeds=neg.cuda(), latents=lat0.cuda(), source_camera=inp["src"].cuda(),
+              target_camera=inp["tgt"].cuda(), source_image_latents=inp["lat"].cuda(), noise_per_step=[n.cuda() for n in noises])
+    model.fourier_projection = None
+    err = rel_l2(got, want)
+    print("full-size 4-step CFG loop rel-L2", err, flush=True)
+    assert torch.isfinite(got).all()
+    assert err <= 5e-2, err
