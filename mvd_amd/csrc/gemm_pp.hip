@@ -706,7 +706,7 @@ int mvd_launch_gemm_pp(const MvdGemmArgs& a, hipStream_t s) {
 bool mvd_gemm_ln_fold_ok(const MvdGemmArgs& a) {
   const MvdASeg& g = a.seg[0];
   if (a.nseg != 1 || g.mode != MVD_A_DENSE || g.c1 || a.splitk > 1 || a.res || a.rowvec || a.out_f32) return false;
-  if (a.Ktot != g.c0 || a.Ktot > 1280) return false;
+  if (a.Ktot != g.c0 || a.Ktot > 640) return false;      // (the 64x64 and 32x32 levels; the small-M kernels fold at every level)
   // measured (tools/probe_lnfold.py, profiles/r02_probe_lnfold.log): the fold saves 36-47 us per launch at C = 320 and 5-19 us
   // at C = 640 -- except for the GEGLU form at C = 640, which loses 9 us (its epilogue fetches the column constants from LDS
   // at every use): that one keeps ln_kernel + the plain kernel

@@ -531,6 +531,10 @@ extern "C" int mvd_gemm_sm_num_tiles(void) { return kNumSmTiles; }
 bool mvd_gemm_sm_plan(const MvdGemmArgs& a, int* tile, int* nstage, int* splitk) {
   const int M = a.M, N = a.N, nkt = a.Ktot / 64;
   if (M > 4608 || a.Ktot % 64 || N % 64) return false;
+  // beyond one image's 32x32 map only SMALL problems: with work for every CU the persistent 128x160 / 256x320 kernels move
+  // half the operand bytes per FLOP (the 8x8 level of a 32-image batch, M = 2048: 6.2 ms through these kernels against
+  // 2.9 ms -- cfg4 kernel classes, round 3)
+  if (M > 1024 && 2.0 * M * (double)N * a.Ktot > 12e9) return false;
   const bool conv = a.seg[0].mode == MVD_A_CONV3;
   if (conv && M >= 4096) return false;          // 64x64-level convolutions: the 128x160 / 256x320 kernels are as fast or faster
   int t = 0;

@@ -335,11 +335,12 @@ def test_layernorm_fold_cfg4_shapes(ops, m, c, nmul, geglu, offset):
     close(got, want, tol=2 ** -6, what=f"ln-fold M={m} C={c} N={n} geglu={geglu}")
 
 
-def test_layernorm_fold_rejects_small_problems(ops):
-    """Shapes the fused kernel does not take (too few 256x320 tiles, N not a multiple of 320) are refused, not mis-run."""
+def test_layernorm_fold_rejects_shapes_no_kernel_takes(ops):
+    """Shapes neither fused kernel takes (256x320 form: N not a multiple of 320; small-M form: M > 4608; C = 1280 at a size only
+    the 256x320 form could run) are refused, not mis-run."""
     from mvd_amd._lib import MvdError
     from mvd_amd.packing import fold_layernorm
-    for m, c, n in [(2048, 1280, 1280), (131072, 320, 384)]:          # too few tiles; N % 320 != 0
+    for m, c, n in [(131072, 320, 384), (8192, 1280, 3840)]:
         wf, cf = fold_layernorm(grnd(n, c).float(), torch.ones(c, device="cuda"), torch.zeros(c, device="cuda"), None, "cuda")
         with pytest.raises(MvdError):
             ops.ln_linear(grnd(m, c), wf, cf)
