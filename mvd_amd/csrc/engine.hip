@@ -21,7 +21,7 @@
 int mvd_launch_silu_to_bf16(const float* x, int64_t n, bf16_t* y, hipStream_t s);
 
 // measurement / bisection switches (bench.py --debug-flags, tools/): bit 0 = no LayerNorm fold through the small-M kernels,
-// bit 1 = small-M kernels never split K, bit 2 = small-M kernels off, bit 3 = no split-KV attention
+// bit 1 = small-M kernels never split K, bit 2 = small-M kernels off, bit 3 = no split-KV attention, bit 4 = no side stream
 static int g_debug_flags = 0;
 extern "C" int mvd_debug_set_flags(int flags) { g_debug_flags = flags; return 0; }
 
@@ -75,6 +75,21 @@ struct mvd_engine {
   // arrival counters of the in-kernel split-K combine (gemm_sm.hip): one zeroed block per entry call, carved from the
   // workspace, every split-K launch of the call takes its own slice (no counter is ever re-used inside a call)
   unsigned int* cnt_base = nullptr; int cnt_used = 0, cnt_cap = 0;
+  // Small batches (infer.py's batch 1): the reference-image encoder pass and the main pass are two chains of small kernels
+  // that each leave most of the chip idle, and the main pass needs the encoder only at its adapter attentions (feature by
+  // feature) -- so the encoder pass is issued on a SIDE STREAM and the main pass waits per feature on an event.
+  hipStream_t side = nullptr;
+  std::vector<hipEvent_t> feat_ev;          // one per feature: its adapter K/V are complete
+  hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+  bool dual_now = false;                    // this forward runs the encoder pass on the side stream
+  int ensure_side_stream() {
+    if (side) return 0;
+    if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) { mvd_set_error("engine: hipStreamCreate failed"); return -3; }
+    feat_ev.resize(feats.size());
+    for (auto& ev : feat_ev) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { mvd_set_error("engine: hipEventCreate failed"); return -3; }
+    if (hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&join_ev, hipEventDisableTiming) != hipSuccess) { mvd_set_error("engine: hipEventCreate failed"); return -3; }
+    return 0;
+  }
   bool share_encoder = false;       // N4: the encoder pass reads weight set 0 (base UNet == image-encoder UNet)
   // hipGraph replay of whole forwards (mvd_engine_set_graph): one instantiated graph per distinct (arguments, cache state)
   struct HostState {                  // what a forward leaves behind on the host side
@@ -95,7 +110,14 @@ struct mvd_engine {
     for (auto& ge : graphs) { (void)hipGraphExecDestroy(ge.x); (void)hipGraphDestroy(ge.g); }
     graphs.clear(); graph_seen.clear();
   }
-  ~mvd_engine() { drop_graphs(); for (hipEvent_t ev : ev_pool) (void)hipEventDestroy(ev); }
+  ~mvd_engine() {
+    drop_graphs();
+    for (hipEvent_t ev : ev_pool) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : feat_ev) if (ev) (void)hipEventDestroy(ev);
+    if (fork_ev) (void)hipEventDestroy(fork_ev);
+    if (join_ev) (void)hipEventDestroy(join_ev);
+    if (side) (void)hipStreamDestroy(side);
+  }
   std::vector<int> temb_off;        // per resnet offset into the fused time_emb_proj output
   int temb_total = 0;
   std::vector<int> tkv_off;         // per transformer column offset into the fused text K/V projection
@@ -134,6 +156,7 @@ struct Ctx {
   int set;          // weight set of the current UNet pass
   bool dry;
   int err = 0;
+  bool nowait = false;   // split-K combines must not wait for other workgroups (kernels of two streams share the chip)
 
   const Weight* W(const std::string& name, int dtype, int64_t numel, int set_override = -1) {
     if (dry) return nullptr;  // sizing run: weights need not be registered
@@ -178,7 +201,7 @@ struct Ctx {
       if (g_debug_flags & 2) sm_S = 1;
       const size_t mark = e->tmp.off;
       if (sm_S > 1) {
-        g.splitk = sm_S; g.part = talloc<float>((size_t)sm_S * g.M * g.N);
+        g.splitk = sm_S; g.splitk_nowait = nowait ? 1 : 0; g.part = talloc<float>((size_t)sm_S * g.M * g.N);
         const int tiles = ((g.M + 63) / 64) * (g.N / 64);           // (an upper bound for every tile shape)
         g.tile_cnt = e->cnt_base + e->cnt_used;
         e->cnt_used += tiles;
@@ -411,6 +434,8 @@ struct UNetPass {
     const int ref_nk = ad ? (int)((int64_t)o.ref_batch * hw / B_) : 0;
     if (ad && (int64_t)ref_nk * B_ != (int64_t)o.ref_batch * hw) { mvd_set_error("adapter: ref tokens %d x %d not divisible by batch %d", o.ref_batch, hw, B_); return -12; }
 
+    // (dual-stream forwards: this feature's adapter K/V come from the encoder pass on the side stream)
+    if (ad && c.e->dual_now && !c.dry && !c.err && hipStreamWaitEvent(c.s, c.e->feat_ev[feat_idx], 0) != hipSuccess) { mvd_set_error("forward: hipStreamWaitEvent failed"); return -3; }
     // ---- attn1 (self) + adapter branch "<feature>_self"
     {
       const int nq = ad ? 4 * C : 3 * C;
@@ -458,6 +483,7 @@ struct UNetPass {
       } else {
         if (!c.dry && !c.err) CHECK(mvd_launch_refnorm(out.p, B_, hw, C, rn, c.s));
         CHECK(c.linear(rn, nullptr, C, 0, M, c.WB(key + ".ref_kv.w", (int64_t)4 * C * C, 0), nullptr, 4 * C, nullptr, 0, c.e->refkv[feat_idx], 4 * C));
+        if (c.e->dual_now && !c.dry && !c.err && hipEventRecord(c.e->feat_ev[feat_idx], c.s) != hipSuccess) { mvd_set_error("forward: hipEventRecord failed"); return -3; }
       }
       if (c.e->rc_keep && !c.dry && !c.err)
         CHECK((int)hipMemcpyAsync(c.e->feat_keep[feat_idx], out.p, (size_t)M * C * sizeof(bf16_t), hipMemcpyDeviceToDevice, c.s));
@@ -752,6 +778,16 @@ int forward_impl(mvd_engine* e, const mvd_forward_args_t& a, hipStream_t s, bool
     }
   }
 
+  // ---- small batches: the encoder pass goes to the side stream (see mvd_engine::side).  `dual` (a function of the shapes only)
+  // decides the workspace layout -- in the sizing runs too; whether the side stream is really used also needs: no graph
+  // capture, no per-launch profiling (one stream each).
+  const bool dual = use_img && !reuse && !ref_only && (int64_t)(a.ref_batch + B) * H * Wd <= 3 * 4096 + 2 * 9216;
+  e->dual_now = dual && !dry && !e->graph_on && !e->prof && !(g_debug_flags & 16);
+  if (e->dual_now) {   // fork in front of everything else: the encoder pass needs nothing of the camera path
+    CHECK(e->ensure_side_stream());
+    if (hipEventRecord(e->fork_ev, s) != hipSuccess || hipStreamWaitEvent(e->side, e->fork_ev, 0) != hipSuccess) { mvd_set_error("forward: stream fork failed"); return -3; }
+  }
+
   // ---- camera path (fp32) -> embedding + FiLM scale/shift per modulator
   std::unordered_map<std::string, std::pair<float*, float*>> film_ss;
   // (running this path on a side stream concurrently with the reference pass was measured: +0.1 %, within noise --
@@ -759,26 +795,41 @@ int forward_impl(mvd_engine* e, const mvd_forward_args_t& a, hipStream_t s, bool
   if (use_cam) CHECK(camera_path(c, a, film_ss));
 
   // ---- reference image encoder pass (frozen UNet at t = 0, plain attention) -> adapter K/V
+  // Small batches: on the side stream, concurrently with the main pass (see mvd_engine::side).  Not under graph capture /
+  // per-launch profiling (one stream each), not for the deferred-statistics form.
   if (use_img && !reuse) {
+    // (dual: the camera path's kernels on the caller's stream may still be using their scoped temporaries when the side
+    //  stream starts -- the encoder pass gets a region of its own behind them)
+    if (dual) e->tmp.off = e->tmp.high;
     const size_t tm = e->tmp.off, am = e->act.off;
+    if (e->dual_now) { c.s = e->side; c.nowait = true; }
     c.set = e->share_encoder ? 0 : 1;
     const int Br = a.ref_batch;
     float* tz = c.talloc<float>(Br);
-    if (!dry) CHECK((int)hipMemsetAsync(tz, 0, Br * sizeof(float), s));
+    if (!dry) CHECK((int)hipMemsetAsync(tz, 0, Br * sizeof(float), c.s));
     const float* tproj = nullptr;
     CHECK(time_path(c, tz, Br, &tproj));
     bf16_t* tx = c.aalloc<bf16_t>((size_t)Br * L * xd);
     Act xin = c.new_act(Br, H, Wd, 64, true);   // im2col rows for conv_in
     if (!dry && !c.err) {
-      CHECK(mvd_launch_f32_to_bf16(a.encoder_text, (int64_t)Br * L * xd, tx, s));
-      CHECK(mvd_launch_im2col_in(a.source_latents, Br, cfg.in_channels, H, Wd, nullptr, nullptr, 0, xin.p, s));
+      CHECK(mvd_launch_f32_to_bf16(a.encoder_text, (int64_t)Br * L * xd, tx, c.s));
+      CHECK(mvd_launch_im2col_in(a.source_latents, Br, cfg.in_channels, H, Wd, nullptr, nullptr, 0, xin.p, c.s));
     }
     PassOpts po; po.capture = true; po.ref_batch = Br;
     po.defer_norm = ref_only; po.stats = e->ref_stats_out;
     UNetPass pass{c, cfg, po, Br, H, Wd, L, tx, tproj};
     CHECK(pass.run(xin, nullptr));
     if (!dry) { e->rc_valid = !ref_only; e->rc_pending = ref_only; }
-    e->tmp.off = tm; e->act.off = am;   // encoder activations are dead; reuse their memory
+    if (dual) {
+      // the encoder pass may still be RUNNING while the main pass is issued: its activations stay, the main pass's scoped
+      // temporaries start behind the encoder's high-water mark.  (Main-pass kernels may rendezvous again: the side stream's
+      // never wait, so every workgroup of a main-pass kernel becomes resident eventually.)
+      e->tmp.off = e->tmp.high;
+      if (e->dual_now && hipEventRecord(e->join_ev, e->side) != hipSuccess) { mvd_set_error("forward: hipEventRecord failed"); return -3; }
+      c.s = s; c.nowait = false;
+    } else {
+      e->tmp.off = tm; e->act.off = am;   // encoder activations are dead; reuse their memory
+    }
   }
   if (ref_only) {
     if (c.err) return c.err;
@@ -801,6 +852,10 @@ int forward_impl(mvd_engine* e, const mvd_forward_args_t& a, hipStream_t s, bool
   PassOpts po; po.adapter = use_img; po.film = use_cam; po.ref_batch = a.ref_batch; po.film_ss = &film_ss;
   UNetPass pass{c, cfg, po, B, H, Wd, L, tx, tproj};
   CHECK(pass.run(xin, a.out));
+  if (e->dual_now) {   // join: everything the side stream did (kept features included) precedes whatever follows on s
+    if (hipStreamWaitEvent(s, e->join_ev, 0) != hipSuccess) { mvd_set_error("forward: stream join failed"); return -3; }
+    e->dual_now = false;
+  }
   if (c.err) return c.err;
   if (!dry && (e->tmp.high + e->act.high > (size_t)e->ws_bytes)) { mvd_set_error("forward: workspace too small"); return -4; }
   return 0;

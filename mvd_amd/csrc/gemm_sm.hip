@@ -318,19 +318,28 @@ __global__ __launch_bounds__(256) void gemm_sm_kernel(const MvdGemmArgs a, const
     if (tid == 0) {
       typedef __attribute__((address_space(1))) unsigned int gu32;
       gu32* c = (gu32*)(a.tile_cnt + tl);
-      __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      int spins = 0, ok = 1;
-      while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)S) {
-        __builtin_amdgcn_s_sleep(8);
-        if (++spins > (1 << 20)) { ok = 0; break; }                     // bounded: a give-up poisons the output (loud, not hung)
+      const unsigned ticket = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a.splitk_nowait) {
+        // no-wait form (a launch that may share the chip with another stream's kernels: nobody may wait for a workgroup that
+        // is not resident yet): the slice that draws the last ticket combines the whole tile, the others leave
+        *flag = ticket == (unsigned)(S - 1) ? 2 : 3;
+      } else {
+        int spins = 0, ok = 1;
+        while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)S) {
+          __builtin_amdgcn_s_sleep(8);
+          if (++spins > (1 << 20)) { ok = 0; break; }                   // bounded: a give-up poisons the output (loud, not hung)
+        }
+        *flag = ok;
       }
-      *flag = ok;
     }
     __syncthreads();
-    const bool gave_up = *flag == 0;
+    const int fl = *flag;
+    if (fl == 3) return;
+    const bool gave_up = fl == 0;
     constexpr int UN = BN / 16, U = (BM / 16) * UN;                     // 16x16 sub-tiles of the tile
     const float alpha_s = a.alpha;
-    for (int u = ks * 4 + wave; u < U; u += 4 * S) {
+    const int u0 = fl == 2 ? wave : ks * 4 + wave, ustep = fl == 2 ? 4 : 4 * S;
+    for (int u = u0; u < U; u += ustep) {
       const int ti = u / UN, tj = u - ti * UN;
       const int m = m0 + ti * 16 + fr, n = n0 + tj * 16 + fq * 4;
       const bool live = m < a.M;
@@ -454,7 +463,7 @@ int launch_sm3(const MvdGemmArgs& a, int nstage, hipStream_t s) {
   const int ntm = (a.M + BM - 1) / BM, ntn = a.N / BN;
   const int S = a.splitk > 1 ? a.splitk : 1;
   const int grid = ntm * ntn * S;
-  if (S > 1) {
+  if (S > 1 && !a.splitk_nowait) {
     // the slices of a tile wait for each other inside the kernel: every workgroup of the grid must be resident at once
     static int occ_lds = -1, occ = 0;
     if (occ_lds != lds) {

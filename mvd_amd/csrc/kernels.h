@@ -44,6 +44,8 @@ struct MvdGemmArgs {
   int splitk;             // > 1: K is split over `splitk` work items per tile; raw fp32 partial tiles go to `part`
   float* part;            // [splitk][M][N] fp32 partials (then mvd_launch_splitk_reduce applies the epilogue)
   int w_blocked;          // gemm_sm.hip only: W is stored as [N/32][K/64] blocks of 32 rows x 64 k in LDS-image order (packing.block_weight)
+  int splitk_nowait;      // gemm_sm.hip split-K: 1 = the slice that arrives last combines the whole tile and nobody waits (launches that
+                          // may share the chip with another stream's kernels); 0 = the slices rendezvous and each combines a share
   unsigned int* tile_cnt; // gemm_sm.hip split-K only: one ZEROED arrival counter per output tile (the slice that takes the last
                           // ticket combines the partials in the kernel: no reduce launch)
   int dbg;                // probe builds only (-DMVD_PROBE, env MVD_GEMM_DEBUG): bit0 skip the output stores, bit1 skip the MFMAs
