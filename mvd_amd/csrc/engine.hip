@@ -75,9 +75,9 @@ struct mvd_engine {
   // arrival counters of the in-kernel split-K combine (gemm_sm.hip): one zeroed block per entry call, carved from the
   // workspace, every split-K launch of the call takes its own slice (no counter is ever re-used inside a call)
   unsigned int* cnt_base = nullptr; int cnt_used = 0, cnt_cap = 0;
-  // Small batches (infer.py's batch 1): the reference-image encoder pass and the main pass are two chains of small kernels
-  // that each leave most of the chip idle, and the main pass needs the encoder only at its adapter attentions (feature by
-  // feature) -- so the encoder pass is issued on a SIDE STREAM and the main pass waits per feature on an event.
+  // The reference-image encoder pass and the main pass are two chains of kernels of which the second needs the first only at
+  // its adapter attentions (feature by feature) -- so the encoder pass is issued on a SIDE STREAM and the main pass waits per
+  // feature on an event.  At batch 1 (infer.py) each chain alone leaves most of the chip idle.
   hipStream_t side = nullptr;
   std::vector<hipEvent_t> feat_ev;          // one per feature: its adapter K/V are complete
   hipEvent_t fork_ev = nullptr, join_ev = nullptr;
@@ -778,10 +778,11 @@ int forward_impl(mvd_engine* e, const mvd_forward_args_t& a, hipStream_t s, bool
     }
   }
 
-  // ---- small batches: the encoder pass goes to the side stream (see mvd_engine::side).  `dual` (a function of the shapes only)
-  // decides the workspace layout -- in the sizing runs too; whether the side stream is really used also needs: no graph
-  // capture, no per-launch profiling (one stream each).
-  const bool dual = use_img && !reuse && !ref_only && (int64_t)(a.ref_batch + B) * H * Wd <= 3 * 4096 + 2 * 9216;
+  // ---- the encoder pass goes to the side stream (see mvd_engine::side): at batch 1 the two passes overlap almost completely
+  // (cfg3 cold 9.8 -> 7.0 ms), at 32 pairs the second stream still fills the tails and the under-filled launches of the deep
+  // levels (cfg4 65.0 -> 63.5 ms, same box).  `dual` (a function of the call's flags only) decides the workspace layout -- in
+  // the sizing runs too; whether the side stream is really used also needs: no graph capture, no per-launch profiling.
+  const bool dual = use_img && !reuse && !ref_only;
   e->dual_now = dual && !dry && !e->graph_on && !e->prof && !(g_debug_flags & 16);
   if (e->dual_now) {   // fork in front of everything else: the encoder pass needs nothing of the camera path
     CHECK(e->ensure_side_stream());
