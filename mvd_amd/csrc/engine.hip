@@ -707,6 +707,40 @@ int camera_path(Ctx& c, const mvd_forward_args_t& a, std::unordered_map<std::str
   float* emb = c.aalloc<float>((size_t)Bc * D);
   c.e->cam_emb = emb; c.e->cam_batch = Bc;
   CHECK(camera_embed(c, a.source_camera, a.target_camera, a.cam_rows, a.fourier_proj, Bc, emb));
+  // all hooked modulators at once when the concatenated slots are registered (packing.pack_camera): 4 launches instead of 4 each
+  const auto mods = modulator_dims(cfg, false);
+  if ((c.dry || c.has("cam.modcat.w0", 0)) && mods.size() <= 16) {
+    const int nm = (int)mods.size(), Hh = D / 2;
+    MvdSegTable seg; memset(&seg, 0, sizeof(seg));
+    seg.n = nm;
+    int tot = 0;
+    for (int i = 0; i < nm; ++i) { tot += 2 * mods[i].second; seg.end[i] = tot; }
+    float* ssbuf = c.aalloc<float>((size_t)B * tot);                  // per modulator: scale [B][dim] | shift [B][dim]
+    const size_t mk = c.e->tmp.off;
+    float* h1 = c.talloc<float>((size_t)Bc * nm * Hh);
+    float* h2 = c.talloc<float>((size_t)Bc * nm * Hh);
+    float* raw = c.talloc<float>((size_t)Bc * tot);
+    const float* w0 = c.WF("cam.modcat.w0", (int64_t)nm * Hh * D, 0);
+    const float* b0 = c.WF("cam.modcat.b0", (int64_t)nm * Hh, 0);
+    const float* g1 = c.WF("cam.modcat.g1", (int64_t)nm * Hh, 0);
+    const float* be1 = c.WF("cam.modcat.be1", (int64_t)nm * Hh, 0);
+    const float* w3 = c.WF("cam.modcat.w3", (int64_t)tot * Hh, 0);
+    const float* b3 = c.WF("cam.modcat.b3", tot, 0);
+    if (!c.dry && !c.err) {
+      CHECK(mvd_launch_skinny_linear(emb, D, Bc, D, w0, 0, b0, nm * Hh, 0, h1, nm * Hh, c.s));
+      CHECK(mvd_launch_layernorm_f32(h1, Bc * nm, Hh, 1e-5f, g1, be1, 1, h2, c.s, nm));
+      CHECK(mvd_launch_skinny_linear_grouped(h2, nm * Hh, Hh, Bc, Hh, w3, b3, tot, seg, raw, tot, c.s));
+      CHECK(mvd_launch_film_params_grouped(raw, Bc, seg, cfg.cam_modulation_strength, ssbuf, B, c.s));
+    }
+    c.e->tmp.off = mk;
+    int c0 = 0;
+    for (int i = 0; i < nm; ++i) {
+      float* sc = ssbuf + (size_t)B * 2 * c0;
+      ss[mods[i].first] = {sc, sc + (size_t)B * mods[i].second};
+      c0 += mods[i].second;
+    }
+    return c.err;
+  }
   for (auto& m : modulator_dims(cfg, false)) {
     float* sc = c.aalloc<float>((size_t)B * m.second);
     float* sh = c.aalloc<float>((size_t)B * m.second);

@@ -147,9 +147,18 @@ int mvd_launch_nhwc_to_nchw_f32(const bf16_t* x, int batch, int hw, int c, float
 // W is fp32 (wbf16 == 0) or bf16 (wbf16 == 1).  act: 0 none, 1 SiLU
 int mvd_launch_skinny_linear(const float* x, int ldx, int batch, int k, const void* w, int wbf16, const float* bias,
                              int n, int act_in, float* y, int ldy, hipStream_t s);
+// grouped forms (the camera modulators batched): output feature o belongs to segment g = the first with o < seg.end[g]; its input
+// row is x + g * xseg (every segment has the same K).  mvd_launch_layernorm_f32: row r uses gamma/beta + (r % nseg) * c.
+struct MvdSegTable { int n; int end[16]; };
+int mvd_launch_skinny_linear_grouped(const float* x, int ldx, int xseg, int batch, int k, const float* w, const float* bias, int n,
+                                     const MvdSegTable& seg, float* y, int ldy, hipStream_t s);
+// FiLM post-processing for all segments at once: raw [batch][seg.end[n-1]] with segment g = [scale_raw(dim_g) | shift_raw(dim_g)];
+// outputs for segment g at out + out_rows * seg.end[g-1]: scale [out_rows][dim_g] then shift [out_rows][dim_g]
+int mvd_launch_film_params_grouped(const float* raw, int batch, const MvdSegTable& seg, float strength, float* out, int out_rows,
+                                   hipStream_t s);
 // row LayerNorm in fp32 with optional SiLU
 int mvd_launch_layernorm_f32(const float* x, int rows, int c, float eps, const float* gamma, const float* beta,
-                             int silu, float* y, hipStream_t s);
+                             int silu, float* y, hipStream_t s, int nseg = 1);
 // sinusoidal timestep embedding [cos|sin] (diffusers flip_sin_to_cos=True, freq_shift 0)
 int mvd_launch_timestep_embedding(const float* t, int batch, int dim, float* y, hipStream_t s);
 // camera front end: relative pose + Fourier features: cams [batch][rows(3|4)][4] fp32 ->

@@ -210,15 +210,23 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const float* __restr
 
 // Vectorised form: one wave computes F output features for up to 32 batch rows, so every x element fetched serves F
 // weight rows (the x re-reads from L2 dominated the one-feature kernel); 16-byte loads of both operands.
-template <bool WBF16, int F>
+// GROUPED: output feature o reads the input segment x + g * xseg, g = the first segment with o < seg.end[g] (segment ends are
+// multiples of F, so a wave's F features share a segment).
+template <bool WBF16, int F, bool GROUPED = false>
 __global__ __launch_bounds__(256) void skinny_linear_vec_kernel(const float* __restrict__ x, int ldx, int batch, int k,
                                                                  const void* __restrict__ wv, const float* __restrict__ bias,
-                                                                 int n, int act_in, float* __restrict__ y, int ldy) {
+                                                                 int n, int act_in, float* __restrict__ y, int ldy,
+                                                                 const MvdSegTable seg = MvdSegTable{}, int xseg = 0) {
   constexpr int BC = 32;
   constexpr int KV = WBF16 ? 8 : 4;          // k elements per lane per iteration (16 bytes of weight)
   const int lane = threadIdx.x & 63;
   const int o0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * F;
   if (o0 >= n) return;
+  if constexpr (GROUPED) {
+    int g = 0;
+    while (g + 1 < seg.n && o0 >= seg.end[g]) ++g;
+    x += (size_t)g * xseg;
+  }
   for (int b0 = 0; b0 < batch; b0 += BC) {
     float acc[BC][F];
 #pragma unroll
@@ -441,6 +449,42 @@ int mvd_launch_skinny_linear(const float* x, int ldx, int batch, int k, const vo
   if (wbf16) hipLaunchKernelGGL(skinny_linear_kernel<true>, dim3(nblk(n, 4)), dim3(256), 0, s, x, ldx, batch, k, w, bias, n, act_in, y, ldy);
   else hipLaunchKernelGGL(skinny_linear_kernel<false>, dim3(nblk(n, 4)), dim3(256), 0, s, x, ldx, batch, k, w, bias, n, act_in, y, ldy);
   return check("skinny_linear");
+}
+
+int mvd_launch_skinny_linear_grouped(const float* x, int ldx, int xseg, int batch, int k, const float* w, const float* bias, int n,
+                                     const MvdSegTable& seg, float* y, int ldy, hipStream_t s) {
+  if (!x || !w || !y || batch <= 0 || batch > 4096 || k <= 0 || (k % 4) || (ldx % 4) || n <= 0 || ldy < n || seg.n < 1 || seg.n > 16 ||
+      seg.end[seg.n - 1] != n || (((uintptr_t)x | (uintptr_t)w) & 15) || (xseg % 4)) { mvd_set_error("skinny_linear_grouped: bad arguments"); return -1; }
+  for (int g = 0; g < seg.n; ++g) if (seg.end[g] % 2) { mvd_set_error("skinny_linear_grouped: segment ends must be even"); return -1; }
+  hipLaunchKernelGGL((skinny_linear_vec_kernel<false, 2, true>), dim3(nblk(n, 8)), dim3(256), 0, s, x, ldx, batch, k, (const void*)w, bias, n, 0, y, ldy, seg, xseg);
+  return check("skinny_linear_grouped");
+}
+
+__global__ void film_params_grouped_kernel(const float* __restrict__ raw, int batch, int ldraw, const MvdSegTable seg, float strength,
+                                           float* __restrict__ out, int out_rows, int total) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;     // over out_rows * (sum of dims)
+  if (i >= total) return;
+  // segment g holds 2 dim_g raw features at raw column seg.end[g-1]; its outputs start at out + out_rows * seg.end[g-1]
+  const int half = seg.end[seg.n - 1] / 2;                 // sum of dims
+  const int r = i / half, cc = i - r * half;               // output row, channel index over all segments
+  int g = 0, c0 = 0;
+  while (g + 1 < seg.n && cc >= seg.end[g] / 2) ++g;
+  c0 = g ? seg.end[g - 1] / 2 : 0;
+  const int dim = seg.end[g] / 2 - c0, ch = cc - c0;
+  const int b = r % batch;                                 // output rows beyond `batch` repeat the inputs cyclically
+  const float* rw = raw + (size_t)b * ldraw + 2 * c0;
+  const float sv = rw[ch], tv = rw[dim + ch];
+  float* o = out + (size_t)out_rows * 2 * c0;
+  o[(size_t)r * dim + ch] = 2.0f * strength / (1.0f + expf(-sv));
+  o[(size_t)out_rows * dim + (size_t)r * dim + ch] = tv * strength;
+}
+
+int mvd_launch_film_params_grouped(const float* raw, int batch, const MvdSegTable& seg, float strength, float* out, int out_rows,
+                                   hipStream_t s) {
+  if (!raw || !out || batch <= 0 || out_rows < batch || seg.n < 1 || seg.n > 16) { mvd_set_error("film_params_grouped: bad arguments"); return -1; }
+  const int total = out_rows * (seg.end[seg.n - 1] / 2);
+  hipLaunchKernelGGL(film_params_grouped_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, raw, batch, seg.end[seg.n - 1], seg, strength, out, out_rows, total);
+  return check("film_params_grouped");
 }
 
 int mvd_launch_timestep_embedding(const float* t, int batch, int dim, float* y, hipStream_t s) {

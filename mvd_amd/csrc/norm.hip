@@ -456,9 +456,10 @@ __global__ __launch_bounds__(256) void refapply_kernel(const bf16_t* __restrict_
 // ---------------------------------------------------------------- fp32 row LayerNorm (camera MLPs)
 __global__ __launch_bounds__(256) void ln_f32_kernel(const float* __restrict__ x, int c, float eps,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      int silu, float* __restrict__ y) {
+                                                      int silu, float* __restrict__ y, int nseg) {
   __shared__ float red[8];
   const int row = blockIdx.x;
+  gamma += (size_t)(row % nseg) * c; beta += (size_t)(row % nseg) * c;     // (grouped form: one affine per segment)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   auto block_sum = [&](float v) -> float {
     v = wave_sum(v);
@@ -597,8 +598,8 @@ int mvd_launch_refnorm(const bf16_t* x, int batch, int hw, int c, bf16_t* y, hip
 }
 
 int mvd_launch_layernorm_f32(const float* x, int rows, int c, float eps, const float* gamma, const float* beta, int silu,
-                             float* y, hipStream_t s) {
-  if (!x || !y || !gamma || !beta || rows <= 0 || c <= 0) { mvd_set_error("layernorm_f32: bad arguments"); return -1; }
-  hipLaunchKernelGGL(ln_f32_kernel, dim3(rows), dim3(256), 0, s, x, c, eps, gamma, beta, silu, y);
+                             float* y, hipStream_t s, int nseg) {
+  if (!x || !y || !gamma || !beta || rows <= 0 || c <= 0 || nseg < 1) { mvd_set_error("layernorm_f32: bad arguments"); return -1; }
+  hipLaunchKernelGGL(ln_f32_kernel, dim3(rows), dim3(256), 0, s, x, c, eps, gamma, beta, silu, y, nseg);
   return check_launch("layernorm_f32");
 }

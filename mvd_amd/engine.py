@@ -72,7 +72,7 @@ class MVDEngine:
 
     def load_camera(self, sd: Dict[str, torch.Tensor]):
         with torch.no_grad():
-            self._register(0, pack_camera(sd, self.device))
+            self._register(0, pack_camera(sd, self.device, len(self.cfg.block_out_channels)))
 
     def load_image_encoder(self, sd: Dict[str, torch.Tensor]):
         with torch.no_grad():

@@ -177,6 +177,17 @@ def pack_unet(sd: Dict[str, torch.Tensor], cfg: UNetConfig, device, adapter: boo
     return out
 
 
-def pack_camera(sd: Dict[str, torch.Tensor], device) -> Dict[str, torch.Tensor]:
-    """Camera encoder stays fp32 (Q9): slots are the reference keys prefixed with ``cam.``."""
-    return {f"cam.{k}": _f32(v, device) for k, v in sd.items()}
+def pack_camera(sd: Dict[str, torch.Tensor], device, num_levels: int = 4) -> Dict[str, torch.Tensor]:
+    """Camera encoder stays fp32 (Q9): slots are the reference keys prefixed with ``cam.``.  In addition the modulator MLPs the
+    hooks address (down_i, up_i, output -- the engine's order; ``mid`` is never addressed, Q3) are stored CONCATENATED
+    (``cam.modcat.*``), so that all of them run as four launches instead of four each (the camera path is ~50 tiny launches
+    in front of a batch-1 forward)."""
+    out = {f"cam.{k}": _f32(v, device) for k, v in sd.items()}
+    names = [f"down_{i}" for i in range(num_levels)] + [f"up_{i}" for i in range(num_levels)] + ["output"]
+    keys = [f"modulators.{n}.{j}.{t}" for n in names for j in (0, 1, 3) for t in ("weight", "bias")]
+    if all(k in sd for k in keys):
+        cat = lambda j, t: torch.cat([sd[f"modulators.{n}.{j}.{t}"].detach().float() for n in names], 0)   # noqa: E731
+        out["cam.modcat.w0"], out["cam.modcat.b0"] = _f32(cat(0, "weight"), device), _f32(cat(0, "bias"), device)
+        out["cam.modcat.g1"], out["cam.modcat.be1"] = _f32(cat(1, "weight"), device), _f32(cat(1, "bias"), device)
+        out["cam.modcat.w3"], out["cam.modcat.b3"] = _f32(cat(3, "weight"), device), _f32(cat(3, "bias"), device)
+    return out
