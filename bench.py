@@ -459,16 +459,18 @@ def main():
             ach = c["flops"] / (c["ms"] * 1e-3) / 1e12
             # HBM bytes per launch of that kernel class from the committed rocprofv3 --pmc passes of this command
             # (FETCH_SIZE x2 + WRITE_SIZE, gfx950 corrections; tools/pmc_summary.py) -- PMC cannot run inside bench.py
-            traffic = None
-            traffic_file = os.path.join("profiles", "r02_pmc_hbm_traffic.json")
-            try:
-                pmc = json.load(open(os.path.join(ROOT, traffic_file)))
+            traffic, traffic_file = None, None
+            import glob
+            for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")), reverse=True):
+                try:
+                    pmc = json.load(open(cand))
+                except (OSError, ValueError):
+                    continue
                 # only a summary taken on THIS kernel source state and THIS workload is quoted (else null)
                 if (pmc.get("_meta", {}).get("kernel_src_sha") == kernel_source_sha() and args.workload == "cfg4" and args.latent == 64
                         and not args.cached and dom in pmc):
-                    traffic = round(pmc[dom]["hbm_bytes_per_launch"])
-            except (OSError, ValueError):
-                pass
+                    traffic, traffic_file = round(pmc[dom]["hbm_bytes_per_launch"]), os.path.relpath(cand, ROOT)
+                    break
             roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA / 1e12,
                         "unit": "TFLOP/s", "frac": round(ach * 1e12 / PEAK_BF16_MFMA, 4), "traffic": traffic,
                         "traffic_source": f"{traffic_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same kernel sources)" if traffic else None,

@@ -118,3 +118,36 @@ def test_small_m_kernels_use_no_scratch_memory():
     assert "scratch_load" not in asm and "scratch_store" not in asm
     import re
     assert not re.search(r"\.vgpr_spill_count:\s*[1-9]", asm) and not re.search(r"\.private_segment_fixed_size:\s*[1-9]", asm)
+
+
+def test_block_weight_layout_is_the_lds_image():
+    """packing.block_weight: [N/32][K/64] blocks of 32 rows x 128 bytes, chunk c of row r in slot c ^ ((r >> 1) & 7)."""
+    from mvd_amd.packing import block_weight
+    n, k = 96, 192
+    w = torch.arange(n * k, dtype=torch.float32).reshape(n, k)
+    b = block_weight(w).reshape(-1)
+    for nn_ in (0, 5, 31, 32, 77, 95):
+        for kk in (0, 7, 8, 63, 64, 100, 191):
+            r, c = nn_ % 32, (kk % 64) // 8
+            off = ((nn_ // 32) * (k // 64) + kk // 64) * 2048 + r * 64 + (c ^ ((r >> 1) & 7)) * 8 + kk % 8
+            assert b[off] == w[nn_, kk]
+
+
+def test_pack_camera_concatenates_the_hooked_modulators():
+    """cam.modcat.*: down_0..3, up_0..3, output (the engine's hook order; `mid` is never addressed, Q3), layer by layer."""
+    from mvd_amd.camera_encoder import CameraEncoder
+    from mvd_amd.packing import pack_camera
+    dims = {"down_0": 320, "down_1": 640, "down_2": 1280, "down_3": 1280, "mid": 1280, "up_0": 1280, "up_1": 1280, "up_2": 640,
+            "up_3": 320, "output": 4}
+    enc = CameraEncoder(output_dim=64, hidden_dim=32, modulation_hidden_dims=dims)
+    sd = enc.state_dict()
+    out = pack_camera(sd, "cpu", 4)
+    order = [f"down_{i}" for i in range(4)] + [f"up_{i}" for i in range(4)] + ["output"]
+    assert out["cam.modcat.w0"].shape == (9 * 32, 64) and out["cam.modcat.g1"].shape == (9 * 32,)
+    tot = sum(2 * dims[n] for n in order)
+    assert out["cam.modcat.w3"].shape == (tot, 32) and out["cam.modcat.b3"].shape == (tot,)
+    off = 0
+    for i, n in enumerate(order):
+        assert torch.equal(out["cam.modcat.w0"][i * 32:(i + 1) * 32], sd[f"modulators.{n}.0.weight"].float())
+        assert torch.equal(out["cam.modcat.w3"][off:off + 2 * dims[n]], sd[f"modulators.{n}.3.weight"].float())
+        off += 2 * dims[n]

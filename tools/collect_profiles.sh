@@ -1,10 +1,11 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun) from the repo root: the judged evidence of one round.
-#   tools/collect_profiles.sh <round-tag, e.g. r02>
-# Writes under gpurun_out/<tag>/: the bench line + per-shape table, the rocprofv3 kernel-trace stats of the same command,
-# two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) summarised by tools/pmc_summary.py, and one SQ-counter pass.
+#   tools/collect_profiles.sh <round-tag, e.g. r03>
+# Writes under gpurun_out/<tag>/: bench lines of every configuration (+ per-shape tables), the rocprofv3 kernel-trace stats of
+# the cfg4 and cfg2 commands, two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) summarised by tools/pmc_summary.py, one
+# GRBM_GUI_ACTIVE pass (shader clock under load, tools/clock_summary.py) and the SQ-counter passes on isolated launches.
 set -e -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -14,10 +15,31 @@ rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch 
 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-check > /dev/null 2> $OUT/pmc_write.err
 python tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_hbm_traffic.json > $OUT/pmc_hbm_traffic.txt
 cp $OUT/pmc_hbm_traffic.json profiles/${TAG}_pmc_hbm_traffic.json
-python bench.py --steps 20 --warmup 5 --shapes-out $OUT/shapes.txt > $OUT/bench_cfg4.json 2> $OUT/bench_cfg4.err
+rocprofv3 --kernel-trace --output-format csv --pmc GRBM_GUI_ACTIVE -d $OUT/pmc_clk -o c -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-check > /dev/null 2> $OUT/pmc_clk.err
+python tools/clock_summary.py $OUT/pmc_clk $OUT/clock_under_load.json > $OUT/clock_under_load.txt || echo "clock summary failed" > $OUT/clock_under_load.txt
+echo "--- cfg4 (the headline configuration, with the CPU baseline)"
+python bench.py --steps 20 --warmup 5 --shapes-out $OUT/shapes_cfg4.txt > $OUT/bench_cfg4.json 2> $OUT/bench_cfg4.err
 cat $OUT/bench_cfg4.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-check > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
-cp $(find $OUT/prof -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof4 -o stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-check > $OUT/bench_cfg4_under_rocprof.json 2> $OUT/rocprof4.err
+cp $(find $OUT/prof4 -name '*kernel_stats.csv' | head -1) $OUT/bench_cfg4_kernel_stats.csv
+echo "--- batch 1"
+python bench.py --workload cfg2 --steps 50 --warmup 5 --no-cpu-baseline --shapes-out $OUT/shapes_cfg2.txt > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof2 -o stats -- python3 bench.py --workload cfg2 --steps 25 --warmup 0 --no-cpu-baseline --no-check --no-profile > $OUT/bench_cfg2_under_rocprof.json 2> $OUT/rocprof2.err
+cp $(find $OUT/prof2 -name '*kernel_stats.csv' | head -1) $OUT/bench_cfg2_kernel_stats.csv
+python bench.py --workload cfg3 --steps 50 --warmup 5 --no-cpu-baseline --shapes-out $OUT/shapes_cfg3.txt > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err
+python bench.py --workload cfg3 --steps 50 --warmup 5 --no-cpu-baseline --debug-flags 16 --no-profile > $OUT/bench_cfg3_one_stream.json 2> /dev/null
+python bench.py --workload cfg3 --cached --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_cfg3_cached.json 2> /dev/null
+python bench.py --cached --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_cfg4_cached.json 2> /dev/null
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --debug-flags 16 --no-profile > $OUT/bench_cfg4_one_stream.json 2> /dev/null
+echo "--- 768 x 768 (96 x 96 latents)"
+for w in cfg2 cfg3 cfg4; do python bench.py --workload $w --latent 96 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_${w}_latent96.json 2> /dev/null; done
+echo "--- seconds per image"
+python bench.py --workload e2e --steps 5 --warmup 1 > $OUT/bench_e2e_512.json 2> /dev/null
+python bench.py --workload e2e --steps 5 --warmup 1 --cached --no-cpu-baseline > $OUT/bench_e2e_512_cached.json 2> /dev/null
+python bench.py --workload e2e --latent 96 --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_e2e_768.json 2> /dev/null
+python bench.py --workload e2e --latent 96 --steps 5 --warmup 1 --cached --no-cpu-baseline > $OUT/bench_e2e_768_cached.json 2> /dev/null
+for f in cfg2 cfg3 cfg3_one_stream cfg3_cached cfg4 cfg4_cached cfg4_one_stream cfg2_latent96 cfg3_latent96 cfg4_latent96; do python -c "import json;d=json.load(open('$OUT/bench_$f.json'));print('$f', d['ms_per_step'], d['value'])"; done
+for f in e2e_512 e2e_512_cached e2e_768 e2e_768_cached; do python -c "import json;d=json.load(open('$OUT/bench_$f.json'));print('$f', d['seconds_per_image'], d['phases_ms'])"; done
 # SQ counters on isolated launches of the hot kernels (tools/pmc_ops.py), a few counters per pass
 i=0
 for CS in "FETCH_SIZE" "WRITE_SIZE" "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" "SQ_INSTS_VMEM SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_WAVES"; do
@@ -27,5 +49,5 @@ done
 python tools/pmc_ops_summary.py $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_sq3 $OUT/pmc_sq4 $OUT/pmc_sq5 > $OUT/pmc_sq_counters.txt || true
 rm -rf $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_sq3 $OUT/pmc_sq4 $OUT/pmc_sq5
 # the raw counter csvs are large: keep the summaries only
-rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/prof
+rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_clk $OUT/prof4 $OUT/prof2
 ls -la $OUT

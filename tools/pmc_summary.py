@@ -9,6 +9,9 @@ CLASSES = {
     "gemm_pp_256x320_dense": r"gemm_pp_kernel<256, 2, 4, 0, false, false>", "gemm_pp_256x320_ln_dense": r"gemm_pp_kernel<256, 2, 4, 0, false, true>",
     "gemm_pp_256x320_conv3x3": r"gemm_pp_kernel<256, 2, 4, [123], false, false>",
     "gemm_pp_256x320_splitk": r"gemm_pp_kernel<256, 2, 4, \d, true, false>", "gemm_pp_256x320_geglu": r"gemm_pp_kernel<256, 4, 2, 0, false, (false|true)>",
+    "gemm_sm_64x64": "gemm_sm_kernel<64, 64,", "gemm_sm_128x64": "gemm_sm_kernel<128, 64,", "gemm_sm_64x128": "gemm_sm_kernel<64, 128,",
+    "gemm_sm_128x128": "gemm_sm_kernel<128, 128,", "gemm_sm_64x160": "gemm_sm_kernel<64, 160,", "gemm_sm_128x160": "gemm_sm_kernel<128, 160,",
+    "gemm_sm_64x320": "gemm_sm_kernel<64, 320,",
     "gemm_128x160": "Cfg<128, 160, 2, 2>",
     "gemm_128x128": "Cfg<128, 128, 2, 2>", "gemm_128x64": "Cfg<128, 64, 2, 2>", "gemm_64x64": "Cfg<64, 64, 2, 2>",
     "attn_4wave": "attn_kernel<4,", "attn_8wave": "attn_kernel<8,", "attn_2wave": "attn_kernel<2,", "attn_1wave": "attn_kernel<1,",
