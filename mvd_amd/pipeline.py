@@ -62,9 +62,11 @@ class MVDDenoiser:
         # Q5: the reference K/V of a previous call (another object) must never be reused by this one
         if hasattr(self.unet, "reset_reference_cache"):
             self.unet.reset_reference_cache()
-        for i, t in enumerate(self.scheduler.timesteps.tolist()):               # host ints: no device sync
+        ts_host = self.scheduler.timesteps.tolist()                             # host ints for the scheduler's coefficients
+        ts_dev = torch.tensor(ts_host, dtype=torch.float32, device=dev)         # ONE upload: a per-step scalar upload would make
+        for i, t in enumerate(ts_host):                                         # the host wait for the previous step's kernels
             x_in = torch.cat([latents] * 2) if guidance_scale > 1.0 else latents  # pipeline.py:141
-            out = self.unet(sample=x_in, timestep=t, encoder_hidden_states=embeds,
+            out = self.unet(sample=x_in, timestep=ts_dev[i], encoder_hidden_states=embeds,
                             cross_attention_kwargs=cross_attention_kwargs, **extra).sample
             if guidance_scale > 1.0:                                            # pipeline.py:156-158
                 out = ops.cfg_combine(out.float().contiguous(), guidance_scale)

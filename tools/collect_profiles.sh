@@ -15,17 +15,21 @@ rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch 
 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-check > /dev/null 2> $OUT/pmc_write.err
 python tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_hbm_traffic.json > $OUT/pmc_hbm_traffic.txt
 cp $OUT/pmc_hbm_traffic.json profiles/${TAG}_pmc_hbm_traffic.json
+rm -rf $OUT/pmc_fetch $OUT/pmc_write
 rocprofv3 --kernel-trace --output-format csv --pmc GRBM_GUI_ACTIVE -d $OUT/pmc_clk -o c -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-check > /dev/null 2> $OUT/pmc_clk.err
-python tools/clock_summary.py $OUT/pmc_clk $OUT/clock_under_load.json > $OUT/clock_under_load.txt || echo "clock summary failed" > $OUT/clock_under_load.txt
+python tools/clock_summary.py $OUT/pmc_clk $OUT/clock_under_load.json > $OUT/clock_under_load.txt 2> $OUT/clock_summary.err || (echo "clock summary failed"; head -3 $(find $OUT/pmc_clk -name '*counter_collection.csv' | head -1)) > $OUT/clock_under_load.txt
+rm -rf $OUT/pmc_clk
 echo "--- cfg4 (the headline configuration, with the CPU baseline)"
 python bench.py --steps 20 --warmup 5 --shapes-out $OUT/shapes_cfg4.txt > $OUT/bench_cfg4.json 2> $OUT/bench_cfg4.err
 cat $OUT/bench_cfg4.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof4 -o stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-check > $OUT/bench_cfg4_under_rocprof.json 2> $OUT/rocprof4.err
 cp $(find $OUT/prof4 -name '*kernel_stats.csv' | head -1) $OUT/bench_cfg4_kernel_stats.csv
+rm -rf $OUT/prof4
 echo "--- batch 1"
 python bench.py --workload cfg2 --steps 50 --warmup 5 --no-cpu-baseline --shapes-out $OUT/shapes_cfg2.txt > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof2 -o stats -- python3 bench.py --workload cfg2 --steps 25 --warmup 0 --no-cpu-baseline --no-check --no-profile > $OUT/bench_cfg2_under_rocprof.json 2> $OUT/rocprof2.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof2 -o stats -- python3 bench.py --workload cfg2 --steps 25 --warmup 1 --no-cpu-baseline --no-check --no-profile > $OUT/bench_cfg2_under_rocprof.json 2> $OUT/rocprof2.err
 cp $(find $OUT/prof2 -name '*kernel_stats.csv' | head -1) $OUT/bench_cfg2_kernel_stats.csv
+rm -rf $OUT/prof2
 python bench.py --workload cfg3 --steps 50 --warmup 5 --no-cpu-baseline --shapes-out $OUT/shapes_cfg3.txt > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err
 python bench.py --workload cfg3 --steps 50 --warmup 5 --no-cpu-baseline --debug-flags 16 --no-profile > $OUT/bench_cfg3_one_stream.json 2> /dev/null
 python bench.py --workload cfg3 --cached --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_cfg3_cached.json 2> /dev/null
@@ -49,5 +53,4 @@ done
 python tools/pmc_ops_summary.py $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_sq3 $OUT/pmc_sq4 $OUT/pmc_sq5 > $OUT/pmc_sq_counters.txt || true
 rm -rf $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_sq3 $OUT/pmc_sq4 $OUT/pmc_sq5
 # the raw counter csvs are large: keep the summaries only
-rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_clk $OUT/prof4 $OUT/prof2
 ls -la $OUT
