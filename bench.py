@@ -190,7 +190,14 @@ def output_check(model, batch, kw, step):
         model.fourier_projection = (torch.randn(model.camera_encoder.output_dim, enc_dim, generator=g) / math.sqrt(enc_dim)).to(batch["sample"].device)
     a, b = step().clone(), step().clone()
     res = {"deterministic": bool(torch.equal(a, b))}
-    assert res["deterministic"], "two forwards of the same inputs differ"
+    if not res["deterministic"]:
+        d = (a.float() - b.float()).abs()
+        bad = (a != b)
+        rows = bad.flatten(1).any(1).nonzero().flatten().tolist()
+        raise AssertionError(f"two forwards of the same inputs differ: {int(bad.sum())} of {a.numel()} elements, max |diff| "
+                             f"{float(torch.nan_to_num(d, nan=-1.0).max()):.3e}, NaNs {int(torch.isnan(a).sum())}/{int(torch.isnan(b).sum())}, "
+                             f"batch rows {rows[:12]}, (b, c, y, x) of the first: {bad.nonzero()[:8].tolist()}, "
+                             f"a/b there: {a[bad][:8].tolist()} / {b[bad][:8].tolist()}")
     cam = {k: v for k, v in kw.items() if k != "source_image_latents"}
     if batch["sample"].shape[0] >= 4:
         with torch.no_grad():

@@ -86,67 +86,48 @@ __global__ void conv_in_kernel(const bf16_t* __restrict__ x, int h, int w, int c
   *reinterpret_cast<u32x4*>(y + bp * cout + g * 8) = o;
 }
 
-// conv_out: one wave per FOUR horizontally adjacent output pixels, lanes split (tap row, 8-channel vector): a lane loads the
-// 6 input columns its 4 pixels' 3 horizontal taps share (18 vectors per tap-row triple instead of 36) and each weight vector
-// once for the 4 pixels.  (One pixel per wave re-read every input vector 9 times and every weight per pixel: 214 us for the
-// 84 MB input of a 32-image batch, 12x off the HBM time.)
+// (Round 3 tried four adjacent pixels per wave -- 2-3x fewer loads -- and went back: correct in every single-process test,
+//  but with a second process on the same GPU (the two-rank bench rehearsal) 2-15 isolated output elements, always the third
+//  pixel of a quad, differed between two forwards of the same inputs in 9 of 17 runs; this form: 0 of 5.  Not understood;
+//  conv_out is 0.3 % of a 32-pair step.)
+// conv_out: one wave per output pixel, lanes split K = 9*C in 16-byte chunks
 __global__ __launch_bounds__(256) void conv_out_kernel(const bf16_t* __restrict__ x, int batch, int h, int w, int c,
                                                         const bf16_t* __restrict__ wt, const float* __restrict__ bias,
                                                         int cout, float* __restrict__ y) {
-  constexpr int PX = 4;
   const int lane = threadIdx.x & 63;
-  const int wq = (w + PX - 1) / PX;                         // pixel quads per row
-  const long quad = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long pix = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int hw = h * w;
-  if (quad >= (long)batch * h * wq) return;
-  const int b = (int)(quad / ((long)h * wq));
-  const int r = (int)(quad - (long)b * h * wq);
-  const int oy = r / wq, ox0 = (r - oy * wq) * PX;
+  if (pix >= (long)batch * hw) return;
+  const int b = pix / hw, p = pix % hw;
+  const int oy = p / w, ox = p % w;
   const int vec = c >> 3;
-  float acc[PX][8];
+  float acc[8];
 #pragma unroll
-  for (int p = 0; p < PX; ++p)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[p][j] = 0.f;
-  for (int q = lane; q < 3 * vec; q += 64) {
-    const int dy = q / vec, v = q - dy * vec;
-    const int iy = oy + dy - 1;
-    if ((unsigned)iy >= (unsigned)h) continue;
-    u32x4 xv[PX + 2];
-#pragma unroll
-    for (int k = 0; k < PX + 2; ++k) {
-      const int ix = ox0 + k - 1;
-      xv[k] = u32x4{0u, 0u, 0u, 0u};
-      if ((unsigned)ix < (unsigned)w) xv[k] = *reinterpret_cast<const u32x4*>(x + ((size_t)b * hw + iy * w + ix) * c + v * 8);
-    }
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int q = lane; q < 9 * vec; q += 64) {
+    const int tap = q / vec, v = q % vec;
+    const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+    if ((unsigned)iy >= (unsigned)h || (unsigned)ix >= (unsigned)w) continue;
+    const u32x4 xv = *reinterpret_cast<const u32x4*>(x + ((size_t)b * hw + iy * w + ix) * c + v * 8);
 #pragma unroll
     for (int co = 0; co < 8; ++co) {
       if (co < cout) {
+        const u32x4 wv = *reinterpret_cast<const u32x4*>(wt + ((size_t)co * 9 + tap) * c + v * 8);
+        float a = acc[co];
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          const u32x4 wv = *reinterpret_cast<const u32x4*>(wt + ((size_t)co * 9 + dy * 3 + dx) * c + v * 8);
-#pragma unroll
-          for (int p = 0; p < PX; ++p) {
-            float a = acc[p][co];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              a = fmaf(bflo(xv[p + dx][j]), bflo(wv[j]), a);
-              a = fmaf(bfhi(xv[p + dx][j]), bfhi(wv[j]), a);
-            }
-            acc[p][co] = a;
-          }
+        for (int j = 0; j < 4; ++j) {
+          a = fmaf(bflo(xv[j]), bflo(wv[j]), a);
+          a = fmaf(bfhi(xv[j]), bfhi(wv[j]), a);
         }
+        acc[co] = a;
       }
     }
   }
 #pragma unroll
   for (int co = 0; co < 8; ++co) {
     if (co < cout) {
-#pragma unroll
-      for (int p = 0; p < PX; ++p) {
-        const float t = wave_sum(acc[p][co]);
-        if (lane == 0 && ox0 + p < w) y[((size_t)b * cout + co) * hw + oy * w + ox0 + p] = t + bias[co];
-      }
+      const float t = wave_sum(acc[co]);
+      if (lane == 0) y[((size_t)b * cout + co) * hw + p] = t + bias[co];
     }
   }
 }
@@ -418,8 +399,8 @@ int mvd_launch_conv_in(const bf16_t* x, int batch, int h, int w, int cin, const 
 int mvd_launch_conv_out(const bf16_t* x, int batch, int h, int w, int c, const bf16_t* wt, const float* bias, int cout,
                         float* y, hipStream_t s) {
   if (!x || !y || !wt || !bias || batch <= 0 || h <= 0 || w <= 0 || (c % 8) || cout <= 0 || cout > 8) { mvd_set_error("conv_out: bad arguments"); return -1; }
-  const long quads = (long)batch * h * ((w + 3) / 4);       // four adjacent pixels per wave
-  hipLaunchKernelGGL(conv_out_kernel, dim3(nblk(quads, 4)), dim3(256), 0, s, x, batch, h, w, c, wt, bias, cout, y);
+  const long pix = (long)batch * h * w;
+  hipLaunchKernelGGL(conv_out_kernel, dim3(nblk(pix, 4)), dim3(256), 0, s, x, batch, h, w, c, wt, bias, cout, y);
   return check("conv_out");
 }
 
