@@ -217,7 +217,18 @@ struct Ctx {
       return r;
     }
     // split-K for tile grids that cannot fill the chip: fp32 partials in scoped workspace + a reduce/epilogue pass
-    const int S = mvd_gemm_pick_splitk(g);
+    int S = mvd_gemm_pick_splitk(g);
+    // While the encoder pass runs beside the main pass (two streams, forward_impl) a launch need not fill the chip by itself --
+    // the other stream's kernels take the idle CUs -- so the two devices that exist only to fill it are dropped: the 256x320
+    // tile is not split along K at 128 tiles (16x16 level; no fp32 partials, no reduce pass), and 100+ tiles of it are preferred
+    // to 512 of the 128x160 tile (measured on one box, cfg4 cold: 65.6 -> 64.6 -> 63.5 ms per step; halving or dropping the
+    // four-way split of the 8x8 level instead: no gain / a loss; profiles/r03_probe_dual_stream_policies.log).
+    int fc = -1;
+    if (e->dual_now && !(g_debug_flags & 32) && !g.geglu && !g.ln_c1 && !g.out_f32 && g.N % 320 == 0 && mvd_gemm_pp_applicable(g)) {
+      const int cfg = mvd_gemm_pick_config(g);
+      if (cfg == 7) S = 1;
+      else if ((long)((g.M + 255) / 256) * (g.N / 320) >= 100) { fc = 7; S = 1; }
+    }
     const size_t mark = e->tmp.off;
     if (S > 1) { g.splitk = S; g.part = talloc<float>((size_t)S * g.M * g.N); }
     static const bool trace = MVD_ENV_INT("MVD_TRACE_GEMM", 0) != 0;
@@ -226,7 +237,7 @@ struct Ctx {
     if (!dry) {
       const double fl = 2.0 * g.M * (double)g.N * g.Ktot;
       e->prof_M = g.M; e->prof_N = g.N; e->prof_K = g.Ktot; e->prof_tag = g.seg[0].mode * 100 + g.geglu * 10 + (S > 1 ? S : 0);
-      r = profiled(e->prof ? gemm_class(g, mvd_gemm_pick_config(g), S) : 0, fl, 0.0, [&] { return mvd_launch_gemm(g, s); });
+      r = profiled(e->prof ? gemm_class(g, mvd_gemm_pick_config(g), S) : 0, fl, 0.0, [&] { return mvd_launch_gemm(g, s, fc); });
       if (!r && S > 1) r = mvd_launch_splitk_reduce(g, s);
     }
     e->tmp.off = mark;

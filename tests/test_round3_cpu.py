@@ -104,13 +104,16 @@ def test_vae_snapshot_that_fails_to_load_is_an_error_not_a_missing_vae(tmp_path)
         _optional_components(str(tmp_path / "snap"), torch.float32)
 
 
-def test_small_m_kernels_use_no_scratch_memory():
-    """hipcc turns a runtime-indexed register array into scratch_load / scratch_store (which also count on vmcnt beside the
-    hand-counted LDS-DMA waits): the small-M GEMM must compile without a single scratch instruction and without spills."""
+@pytest.mark.parametrize("name", ["gemm_sm", "gemm_pp"])
+def test_hand_pipelined_gemms_use_no_scratch_memory(name):
+    """hipcc turns a runtime-indexed register array -- or one live value too many in a 256-register kernel -- into scratch_load /
+    scratch_store, which also count on vmcnt beside the hand-counted LDS-DMA waits: the small-M GEMM and the ping-pong GEMM
+    (every instantiation, the split-K forms with their in-kernel combine included) must compile without a single scratch
+    instruction and without spills."""
     import tempfile
-    src = os.path.join(ROOT, "mvd_amd", "csrc", "gemm_sm.hip")
+    src = os.path.join(ROOT, "mvd_amd", "csrc", name + ".hip")
     with tempfile.TemporaryDirectory() as d:
-        out = os.path.join(d, "gemm_sm.s")
+        out = os.path.join(d, name + ".s")
         r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", src, "-o", out],
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
