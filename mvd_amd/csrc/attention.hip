@@ -508,6 +508,218 @@ __global__ __launch_bounds__(64 * NW, VSUM ? 4 : ((NW == 4 && NSUB == 2) ? 3 : 2
 }
 
 #ifdef MVD_PROBE   // measurement-only kernels from here to the matching #endif (tools/build_variant.py <tag> -DMVD_PROBE)
+// ---------------------------------------------------------------- 64 queries per wave (engine form only; experiment)
+// Measured (profiles/r03_probe_attention_q64.log): 4096 x 4096 x 5 heads x 32 pairs on random data 790 -> 737 us, but IN SITU
+// (the forward's own activations, where the 32-query kernel already runs 1.05-1.08 PFLOP/s) 1051 vs 1055 TFLOP/s -- nothing --
+// and at 9216 keys (96 x 96 latents) the step is 1 % slower; shorter sequences lose outright.  Probe builds only.
+// The engine form (PRE + DMA + VSUM) with TWO 32-query sub-tiles per wave: every K fragment (ds_read_b128) and every V^T
+// fragment (two ds_read_b64_tr_b16) feeds two MFMAs instead of one -- half the LDS reads and half the per-tile fixed costs
+// (barrier, DMA issue, loop) per FLOP -- and the two sub-tiles' softmax / MFMA streams are independent, so one's
+// exponentials can issue under the other's MFMAs inside ONE wave.  The price is registers: 2 x (32 score + 32 output + 16
+// running-max tile + 16 Q) + ... ~ 250, i.e. TWO waves per SIMD instead of four.  NW waves x 64 queries per workgroup.
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_q64_kernel(const MvdAttnArgs a) {
+  constexpr int NT = 64 * NW, QS = 2, NSUB = 2;
+  constexpr int QB = 32 * NW * QS;
+  constexpr int KV_TILE = 32 * NSUB;
+  constexpr int TILE_BYTES = KV_TILE * 128;
+  constexpr int LD_IT = (KV_TILE * 8) / NT;
+  static_assert((KV_TILE * 8) % NT == 0 && (NT / 8) % 16 == 0, "tile must divide over threads; DMA rows of a lane share the swizzle pattern");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];         // 4 * TILE_BYTES: K0 K1 V0 V1
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane & 31, lh = lane >> 5;
+  int qb_, head, bz;
+  attn_block(a, qb_, head, bz);
+  const int pi = bz / a.batch;
+  bz -= pi * a.batch;
+  const MvdAttnProblem& P = a.p[pi];
+  const int nq = P.nq, nk = P.nk;
+  const int qblk0 = qb_ * QB;
+  if (qblk0 >= nq) return;
+
+  const bf16_t* qp = P.q + (size_t)bz * P.bsq + head * 64;
+  const bf16_t* kp = P.k + (size_t)bz * P.bsk + head * 64;
+  const bf16_t* vp = P.v + (size_t)bz * P.bsv + head * 64;
+  bf16_t* op = P.o + (size_t)bz * P.bso + head * 64;
+
+  // Q fragments live in LDS (behind the K/V stages: 8 KB per wave, K's swizzle) and are re-read per tile -- 32 registers this
+  // kernel does not have; each wave writes and reads only its own rows
+  unsigned char* sq = smem + 4 * TILE_BYTES + wave * (QS * 32 * 128);
+#pragma unroll
+  for (int u = 0; u < QS; ++u) {
+    const int qrow = qblk0 + (wave * QS + u) * 32 + lq;
+    const int qrow_c = qrow < nq ? qrow : nq - 1;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      *reinterpret_cast<bf16x8*>(sq + u * 4096 + k_off(lq, ks * 2 + lh)) = *reinterpret_cast<const bf16x8*>(qp + (size_t)qrow_c * P.ldq + ks * 16 + lh * 8);
+  }
+
+  const int ld_kc = tid & 7, ld_row = tid >> 3;
+  const int ldk = P.ldk, ldv = P.ldv;
+  typedef __attribute__((address_space(3))) void lds_void_t;
+  __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(kp), 0, (nk - 1) * ldk * 2 + 128, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vp), 0, (nk - 1) * ldv * 2 + 128, 0x00020000);
+  const unsigned dma_ko = (unsigned)ld_row * (unsigned)ldk * 2u + ((ld_kc ^ ((ld_row >> 1) & 7)) << 4);
+  const unsigned dma_vo = (unsigned)ld_row * (unsigned)ldv * 2u + ((ld_kc ^ (((ld_row >> 1) & 1) << 2)) << 4);
+  auto dma_tile = [&](int kb, int st) {
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    unsigned char* dk = smem + st * TILE_BYTES + wave_s * 1024;
+    unsigned char* dv = smem + (2 + st) * TILE_BYTES + wave_s * 1024;
+#pragma unroll
+    for (int i = 0; i < LD_IT; ++i) {
+      const int row0 = kb * KV_TILE + i * (NT / 8);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lds_void_t*)(dk + i * (NT / 8) * 128), 16, (int)dma_ko, row0 * ldk * 2, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lds_void_t*)(dv + i * (NT / 8) * 128), 16, (int)dma_vo, row0 * ldv * 2, 0, 0);
+    }
+  };
+
+  f32x16 o0[QS], o1[QS], negm[QS];
+  f32x4 lacc[QS];
+  float m_run[QS];
+#pragma unroll
+  for (int u = 0; u < QS; ++u) { o0[u] = f32x16{}; o1[u] = f32x16{}; negm[u] = f32x16{}; lacc[u] = f32x4{0.f, 0.f, 0.f, 0.f}; m_run[u] = 0.f; }
+  bf16x8 sel;                                  // (the selector of attn_kernel's VSUM form)
+  {
+    const int sm = lane & 15, sg = (lane >> 4) & 1;
+    const __bf16 one = (sm == sg && sm < 2) ? (__bf16)1.0f : (__bf16)0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sel[j] = one;
+  }
+
+  const int nkb = (nk + KV_TILE - 1) / KV_TILE;
+  dma_tile(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int tr_i = lane & 15;
+  const int tr_q = tr_i >> 2, tr_p = tr_i & 3;
+  const int tr_dcol = ((lane >> 4) & 1) * 16 + tr_p * 4;
+  const int tr_base0 = v_off(4 * lh + tr_q, tr_dcol >> 3) + (tr_dcol & 7) * 2;
+  const int tr_base1 = tr_base0 ^ 64;
+  int k_base[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) k_base[ks] = k_off(lq, ks * 2 + lh);
+
+  for (int kb = 0; kb < nkb; ++kb) {
+    const int cur = kb & 1;
+    const bool more = kb + 1 < nkb;
+    if (more) dma_tile(kb + 1, cur ^ 1);
+    const unsigned char* sk = smem + cur * TILE_BYTES;
+    const unsigned char* sv = smem + (2 + cur) * TILE_BYTES;
+
+    // ---- S^T = K.Q^T: one K fragment, two query sub-tiles
+    f32x16 s[QS][NSUB];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int t = 0; t < NSUB; ++t) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + k_base[ks] + t * 32 * 128);
+#pragma unroll
+        for (int u = 0; u < QS; ++u) {
+          const bf16x8 qfr = *reinterpret_cast<const bf16x8*>(sq + u * 4096 + k_base[ks]);
+          if (ks == 0) s[u][t] = mfma_from(kf, qfr, negm[u]);
+          else s[u][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qfr, s[u][t], 0, 0, 0);
+        }
+      }
+    }
+    if (kb * KV_TILE + KV_TILE > nk) {
+#pragma unroll
+      for (int u = 0; u < QS; ++u)
+#pragma unroll
+        for (int t = 0; t < NSUB; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kb * KV_TILE + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (key >= nk) s[u][t][r] = NEG_BIG;
+          }
+    }
+    // ---- online softmax, deferred rescale; one vote for both sub-tiles
+    float mx[QS];
+#pragma unroll
+    for (int u = 0; u < QS; ++u) {
+      mx[u] = s[u][0][0];
+#pragma unroll
+      for (int t = 0; t < NSUB; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx[u] = fmaxf(mx[u], s[u][t][r]);
+    }
+    if (kb == 0 || !__all(fmaxf(mx[0], mx[1]) <= RESCALE_LOG2)) {
+#pragma unroll
+      for (int u = 0; u < QS; ++u) {
+        const float mxu = pair_max(mx[u]);
+        const float delta = kb == 0 ? mxu : fmaxf(mxu, 0.f);
+        if (kb != 0) {
+          const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { o0[u][r] *= alpha; o1[u][r] *= alpha; }
+          lacc[u][0] *= alpha;
+          lacc[u][1] *= __shfl(alpha, (lane + 16) & 63, 64);
+        }
+        m_run[u] += delta;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[u][r] = -m_run[u];
+#pragma unroll
+        for (int t = 0; t < NSUB; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[u][t][r] -= delta;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < QS; ++u)
+#pragma unroll
+      for (int t = 0; t < NSUB; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[u][t][r] = __builtin_amdgcn_exp2f(s[u][t][r]);
+
+    // ---- O^T += V^T . P^T: one V^T fragment, two query sub-tiles
+#pragma unroll
+    for (int st = 0; st < 2 * NSUB; ++st) {
+      bf16x8 pb[QS];
+#pragma unroll
+      for (int u = 0; u < QS; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pb[u][j] = (__bf16)s[u][st >> 1][8 * (st & 1) + j];
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const int offA = (dt == 0 ? tr_base0 : tr_base1) + st * 16 * 128;
+        const int offB = offA + 8 * 128;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sv + offA));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sv + offB));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const bf16x8 vf = __builtin_bit_cast(bf16x8, both);
+#pragma unroll
+        for (int u = 0; u < QS; ++u) {
+          if (dt == 0) o0[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[u], o0[u], 0, 0, 0);
+          else         o1[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[u], o1[u], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < QS; ++u) lacc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sel, pb[u], lacc[u], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int u = 0; u < QS; ++u) {
+    const float d0 = __shfl(lacc[u][0], lq & 15, 64), d1 = __shfl(lacc[u][1], lq & 15, 64);
+    const float inv = 1.0f / (lq < 16 ? d0 : d1);
+    const int qrow = qblk0 + (wave * QS + u) * 32 + lq;
+    if (qrow < nq) {
+      bf16_t* orow = op + (size_t)qrow * P.ldo;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2 w0 = {pack2bf(o0[u][4 * g] * inv, o0[u][4 * g + 1] * inv), pack2bf(o0[u][4 * g + 2] * inv, o0[u][4 * g + 3] * inv)};
+        u32x2 w1 = {pack2bf(o1[u][4 * g] * inv, o1[u][4 * g + 1] * inv), pack2bf(o1[u][4 * g + 2] * inv, o1[u][4 * g + 3] * inv)};
+        *reinterpret_cast<u32x2*>(orow + 8 * g + 4 * lh) = w0;
+        *reinterpret_cast<u32x2*>(orow + 32 + 8 * g + 4 * lh) = w1;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Software-pipelined variant (prescaled Q, 64-key tiles, 4 waves x 32 queries, two waves per SIMD / 256 registers):
 // the S^T = K.Q^T MFMAs of tile t+1 are issued UNDER the softmax of tile t (their accumulator is a second register
@@ -966,6 +1178,26 @@ __global__ __launch_bounds__(512, 2) void attn_pp_kernel(const MvdAttnArgs a) {
 
 thread_local int g_last_attn[2] = {0, 0};
 static int g_attn_pipe_override = 0;
+static int g_attn_q64_override = 0;     // measurement hook (probe builds): 64 queries per wave, 4 (2) or 2 (1) waves per workgroup
+
+#ifdef MVD_PROBE
+template <int NW>
+int launch_q64(const MvdAttnArgs& a, int maxq, hipStream_t s) {
+  const int qb = 64 * NW;
+  dim3 grid(((maxq + qb - 1) / qb) * a.heads * a.batch * a.nprob);
+  g_last_attn[0] = NW; g_last_attn[1] = (int)grid.x;
+  static bool init = false;
+  if (!init) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_q64_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32 * 2 * 128 + NW * 8192);
+    if (e != hipSuccess) { mvd_set_error("attention (64 queries per wave): hipFuncSetAttribute: %s", hipGetErrorString(e)); return -2; }
+    init = true;
+  }
+  hipLaunchKernelGGL((attn_q64_kernel<NW>), grid, dim3(64 * NW), 4 * 32 * 2 * 128 + NW * 8192, s, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { mvd_set_error("attention (64 queries per wave) launch: %s", hipGetErrorString(e)); return -3; }
+  return 0;
+}
+#endif
 
 template <int NW, int NSUB>
 int launch_nw(const MvdAttnArgs& a, int maxq, hipStream_t s) {
@@ -1018,6 +1250,8 @@ static int g_attn_nw_override = -1;
 // measurement hook (tools/, bench.py --attn-nw): log2 of the waves per workgroup for every later launch, -1 = heuristic
 // (nw_log2 + 16: additionally the software-pipelined 4-wave variant)
 extern "C" int mvd_debug_set_attention_nw(int nw_log2) {
+  g_attn_q64_override = nw_log2 >= 32 ? nw_log2 - 32 : 0;
+  if (nw_log2 >= 32) nw_log2 = 2;
   g_attn_pipe_override = nw_log2 >= 16;
   g_attn_nw_override = nw_log2 >= 16 ? nw_log2 - 16 : nw_log2;
   return 0;
@@ -1072,6 +1306,13 @@ int mvd_launch_attention(const MvdAttnArgs& a, hipStream_t s) {
       if ((size_t)a.p[i].nk * (a.p[i].ldk > a.p[i].ldv ? a.p[i].ldk : a.p[i].ldv) * 2 >= ((size_t)1 << 31)) { mvd_set_error("attention: split-KV operand too large for buffer addressing"); return -1; }
     return launch_nw<4, 2>(a, maxq, s);
   }
+#ifdef MVD_PROBE
+  if (g_attn_q64_override && a.prescaled && maxq >= 256 && a.nsplit <= 1) {     // experiment: 64 queries per wave (see attn_q64_kernel)
+    for (int i = 0; i < a.nprob; ++i)
+      if ((size_t)a.p[i].nk * (a.p[i].ldk > a.p[i].ldv ? a.p[i].ldk : a.p[i].ldv) * 2 >= ((size_t)1 << 31)) { mvd_set_error("attention: operand too large for buffer addressing"); return -1; }
+    return g_attn_q64_override == 1 ? launch_q64<2>(a, maxq, s) : launch_q64<4>(a, maxq, s);
+  }
+#endif
   switch (mvd_attention_pick_nw(a)) {
 #ifdef MVD_PROBE   // (8-wave workgroups and 128-key tiles: measured slower everywhere, probe builds only)
     case 3: return launch_nw<8, 2>(a, maxq, s);
