@@ -102,7 +102,9 @@ MVD_DEVINL void attn_block(const MvdAttnArgs& a, int& qb, int& head, int& bz, in
 // 12 accumulator registers less, which keeps the kernel at 128 registers: FOUR waves per SIMD.
 // SPLIT (engine form only): split-KV, see MvdAttnArgs::nsplit.
 template <int NW, int NSUB, bool PRE, bool DMA = false, bool VSUM = false, bool SPLIT = false>
-__global__ __launch_bounds__(64 * NW, VSUM ? 4 : ((NW == 4 && NSUB == 2) ? 3 : 2)) void attn_kernel(const MvdAttnArgs a) {
+// (SPLIT runs on a nearly empty chip -- that is why it exists -- so it is compiled for three waves per SIMD: at four, its merge
+//  epilogue spilled two registers to scratch)
+__global__ __launch_bounds__(64 * NW, SPLIT ? 3 : (VSUM ? 4 : ((NW == 4 && NSUB == 2) ? 3 : 2))) void attn_kernel(const MvdAttnArgs a) {
   static_assert(!SPLIT || (PRE && DMA && VSUM), "split-KV exists for the engine form");
   constexpr int NT = 64 * NW;
   constexpr int QB = 32 * NW;
