@@ -308,6 +308,8 @@ def test_layernorm_cfg4_shapes(ops, rows, c):
     (131072, 320, 1, False, 0.3),     # ln2 -> q (no adapter)
     (32768, 640, 4, False, 0.3),
     (32768, 640, 2, False, 8.0),      # rows with |mean| = 8 std: the E[x^2] - mean^2 form must hold up
+    (32768, 640, 2, False, 100.0),    # |mean| ~ 77 std (massive-activation rows): fp32 sums of bf16 squares keep ~11 bits of the
+    (131072, 320, 1, False, -60.0),   #   variance there, and acc - mean * c1 cancels exactly (c1 from the same bf16 weights)
     (131072, 320, 8, True, -2.0),     # ln3 -> ff1 + GEGLU (the C = 640 GEGLU keeps the separate LayerNorm: measured slower fused)
 ])
 def test_layernorm_fold_cfg4_shapes(ops, m, c, nmul, geglu, offset):

@@ -447,7 +447,9 @@ def test_rows_beyond_m_are_never_written(ops):
 
 @pytest.mark.parametrize("m,c,nmul,geglu,offset", [(300, 320, 3, False, 0.3), (4096, 320, 1, False, 0.3), (1024, 640, 3, False, 4.0),
                                                    (256, 1280, 3, False, 0.3), (64, 1280, 1, False, -2.0), (4096, 320, 8, True, 0.3),
-                                                   (1024, 640, 8, True, 0.3), (256, 1280, 8, True, 1.0), (64, 1280, 8, True, 0.3)])
+                                                   (1024, 640, 8, True, 0.3), (256, 1280, 8, True, 1.0), (64, 1280, 8, True, 0.3),
+                                                   (1024, 640, 3, False, 100.0), (256, 1280, 3, False, -130.0),   # |mean| ~ 60-75 std
+                                                   (4096, 320, 8, True, 90.0)])
 def test_sm_ln_linear(ops, m, c, nmul, geglu, offset):
     """LayerNorm folded into the small-M GEMM (batch-1 shapes of every level): LayerNorm(x).W^T + b from the un-normalised rows."""
     from mvd_amd.packing import fold_layernorm, _geglu_rows
