@@ -35,6 +35,7 @@ python bench.py --workload cfg3 --steps 50 --warmup 5 --no-cpu-baseline --debug-
 python bench.py --workload cfg3 --cached --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_cfg3_cached.json 2> /dev/null
 python bench.py --cached --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_cfg4_cached.json 2> /dev/null
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --debug-flags 16 --no-profile > $OUT/bench_cfg4_one_stream.json 2> /dev/null
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --debug-flags 32 --no-profile > $OUT/bench_cfg4_two_streams_single_stream_launch_policy.json 2> /dev/null
 echo "--- 768 x 768 (96 x 96 latents)"
 for w in cfg2 cfg3 cfg4; do python bench.py --workload $w --latent 96 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_${w}_latent96.json 2> /dev/null; done
 echo "--- seconds per image"
@@ -42,7 +43,7 @@ python bench.py --workload e2e --steps 5 --warmup 1 > $OUT/bench_e2e_512.json 2>
 python bench.py --workload e2e --steps 5 --warmup 1 --cached --no-cpu-baseline > $OUT/bench_e2e_512_cached.json 2> /dev/null
 python bench.py --workload e2e --latent 96 --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_e2e_768.json 2> /dev/null
 python bench.py --workload e2e --latent 96 --steps 5 --warmup 1 --cached --no-cpu-baseline > $OUT/bench_e2e_768_cached.json 2> /dev/null
-for f in cfg2 cfg3 cfg3_one_stream cfg3_cached cfg4 cfg4_cached cfg4_one_stream cfg2_latent96 cfg3_latent96 cfg4_latent96; do python -c "import json;d=json.load(open('$OUT/bench_$f.json'));print('$f', d['ms_per_step'], d['value'])"; done
+for f in cfg2 cfg3 cfg3_one_stream cfg3_cached cfg4 cfg4_cached cfg4_one_stream cfg4_two_streams_single_stream_launch_policy cfg2_latent96 cfg3_latent96 cfg4_latent96; do python -c "import json;d=json.load(open('$OUT/bench_$f.json'));print('$f', d['ms_per_step'], d['value'])"; done
 for f in e2e_512 e2e_512_cached e2e_768 e2e_768_cached; do python -c "import json;d=json.load(open('$OUT/bench_$f.json'));print('$f', d['seconds_per_image'], d['phases_ms'])"; done
 # SQ counters on isolated launches of the hot kernels (tools/pmc_ops.py), a few counters per pass
 i=0
