@@ -17,7 +17,9 @@
 //                   through ds_read_b64_tr_b16 (hardware transpose read).
 //   softmax         exp2 domain, raw v_exp_f32; generic form: scale folded into one v_fma; engine form (PRE): the scale
 //                   lives in the packed to_q weights and -running_max is the C operand of the first MFMA.  The
-//                   rescale of O is DEFERRED until some row's max grew by > 2^6.  Denominators: a V^T tile whose
+//                   rescale of O is DEFERRED until some row's max grew by > 2^6 -- and in the engine form not looked for at
+//                   all: the first tile's maximum stays, a non-finite denominator triggers a checked re-run (LAZY, below).
+//                   Denominators: a V^T tile whose
 //                   row 0 is all ones (matrix pipe), or -- engine form (VSUM) -- one 16x16x32 MFMA per P fragment against a 0/1 selector (4 registers).
 // KV tiles hold NSUB x 32 keys: 64 by default.  The 128-key variant halves the per-tile fixed costs
 // (barrier, max reduction tree, rescale test, loader address math) but loses a wave per SIMD and
@@ -32,6 +34,7 @@
 // The engine's kernel is attn_kernel<4, 2, PRE, DMA, VSUM>: 4 waves x 32 queries, 128 VGPRs, four workgroups per CU,
 // workgroups dealt to the XCDs so that all query blocks of a (batch, head) pair share one L2 (attn_block).
 #include <stdlib.h>
+#include <type_traits>
 #include "kernels.h"
 
 namespace {
@@ -244,10 +247,6 @@ __global__ __launch_bounds__(64 * NW, SPLIT ? 3 : (VSUM ? 4 : ((NW == 4 && NSUB 
   const int nkb_all = (nk + KV_TILE - 1) / KV_TILE;
   const int kb0 = SPLIT ? (sp * nkb_all) / nsplit : 0;                 // this workgroup's key tiles [kb0, nkb)
   const int nkb = SPLIT ? ((sp + 1) * nkb_all) / nsplit : nkb_all;
-  if constexpr (DMA) { dma_tile(kb0, 0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-  load_tile(kb0);
-  store_tile(0);
-  __syncthreads();
 
   // transposed-read lane geometry (see header): 16-lane group g reads a 4-key x 16-dim block
   const int tr_i = lane & 15;
@@ -261,6 +260,25 @@ __global__ __launch_bounds__(64 * NW, SPLIT ? 3 : (VSUM ? 4 : ((NW == 4 && NSUB 
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) k_base[ks] = k_off(lq, ks * 2 + lh);
 
+  // LAZY (engine form): the running max is set by the FIRST tile and then left alone -- no per-tile row maximum (16 v_max3 per
+  // 32 x 32 scores), no vote, no rescale branch.  Nothing in online softmax needs m to be the true maximum: O and l are both
+  // scaled by 2^(m_true - m), which cancels in O / l; what it needs is that 2^(s - m) neither overflows (s - m < 128: P is bf16,
+  // the sums fp32) nor that every term underflows (the first tile's maximum contributes exactly 1).  A later score more than
+  // ~100 above the first tile's maximum -- 69 nats; never seen -- makes a denominator non-finite: detected behind the loop,
+  // and the workgroup then re-runs its tiles with the checked (deferred-rescale) loop.  CHK = checked.
+#ifdef MVD_ATTN_NO_LAZY                 // (A/B builds)
+  constexpr bool LAZY = false;
+#else
+  constexpr bool LAZY = PRE && DMA && VSUM;
+#endif
+  auto run_tiles = [&](auto CHK) {
+  constexpr bool chk = decltype(CHK)::value;
+  o0 = f32x16{}; o1 = f32x16{}; ol = f32x16{}; lacc = f32x4{0.f, 0.f, 0.f, 0.f};
+  m_run = PRE ? 0.f : NEG_BIG; negm = f32x16{};
+  if constexpr (DMA) { dma_tile(kb0, 0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  load_tile(kb0);
+  store_tile(0);
+  __syncthreads();
   for (int kb = kb0; kb < nkb; ++kb) {
     const int cur = (kb - kb0) & 1;
     const bool more = kb + 1 < nkb;
@@ -295,11 +313,14 @@ __global__ __launch_bounds__(64 * NW, SPLIT ? 3 : (VSUM ? 4 : ((NW == 4 && NSUB 
         }
     }
     // ---- online softmax (this lane: one query, half of the tile's keys; partner lane^32 has the rest)
-    float mx = s[0][0];
+    float mx = 0.f;
+    if (chk || kb == kb0) {
+      mx = s[0][0];
 #pragma unroll
-    for (int t = 0; t < NSUB; ++t)
+      for (int t = 0; t < NSUB; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
+    }
     // (the vote below runs over all 64 lanes, so it needs no exchange with the partner half-wave: the engine form combines
     //  the two halves of a row only inside the rare rescale branch)
     if constexpr (!(PRE && VSUM)) mx = pair_max(mx);
@@ -309,7 +330,7 @@ __global__ __launch_bounds__(64 * NW, SPLIT ? 3 : (VSUM ? 4 : ((NW == 4 && NSUB 
     if constexpr (PRE) {
       // s holds score - m_run (exp2 domain).  The first tile always sets the running max (m_run starts at 0, so a row
       // whose scores are all far below zero would otherwise underflow every P).
-      if (kb == kb0 || !__all(mx <= RESCALE_LOG2)) {
+      if (kb == kb0 || (chk && !__all(mx <= RESCALE_LOG2))) {
         if constexpr (VSUM) mx = pair_max(mx);
         const float delta = kb == kb0 ? mx : fmaxf(mx, 0.f);     // m_new - m_run
         if (kb != kb0) {
@@ -396,6 +417,15 @@ __global__ __launch_bounds__(64 * NW, SPLIT ? 3 : (VSUM ? 4 : ((NW == 4 && NSUB 
     if (more) store_tile(cur ^ 1);
     if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+  }
+  };   // run_tiles
+  if constexpr (LAZY) {
+    run_tiles(std::false_type{});
+    // lanes 0..15 hold the complete denominators of queries n and n + 16 (see lacc): anything not comfortably finite -> redo checked
+    const int bad = (lane < 16 && !(lacc[0] < 1.0e30f && lacc[1] < 1.0e30f)) ? 1 : 0;
+    if (__syncthreads_or(bad)) run_tiles(std::true_type{});
+  } else {
+    run_tiles(std::true_type{});
   }
 
   // ---- epilogue: O[q][d] = O^T / l ; lane holds d = 32*dt + (r&3) + 8*(r>>2) + 4*lh

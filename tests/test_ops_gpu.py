@@ -472,6 +472,32 @@ def test_sm_ln_linear(ops, m, c, nmul, geglu, offset):
         assert torch.equal(got, ops.ln_linear(xc, wf, cf, geglu=geglu)), "fused LayerNorm GEMM is not bit-deterministic"
 
 
+@pytest.mark.parametrize("nq,nk,jump_at,nsplit", [(256, 640, 64, 1), (200, 1111, 512, 1), (256, 1280, 700, 2), (4096, 4096, 3000, 1)])
+def test_attention_running_max_fallback(ops, nq, nk, jump_at, nsplit):
+    """The engine form takes its running max from the first key tile and checks nothing afterwards; scores that later rise by more
+    than 2^128 over it make the denominators non-finite, which the workgroup detects behind its loop and answers by re-running
+    its tiles with the checked (deferred-rescale) loop.  Here the scores of keys >= jump_at lie ~190 (exp2 domain) above the
+    earlier ones for the first half of the queries (the other half never overflows: both paths in one launch)."""
+    B, heads = 2, 2
+    C = heads * 64
+    g = torch.Generator().manual_seed(5)
+    q = 0.05 * torch.randn(B, nq, C, generator=g)
+    k = 0.05 * torch.randn(B, nk, C, generator=g)
+    v = torch.randn(B, nk, C, generator=g)
+    q[:, : nq // 2] += 1.0                    # q.k = 64 * 1.0 * (+-1.5) = +-96 for those queries
+    k[:, :jump_at] -= 1.5
+    k[:, jump_at:] += 1.5
+    qs, k, v = q.to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16)
+    sp = lambda t, n: t.double().view(B, n, heads, 64).transpose(1, 2)  # noqa: E731
+    want = F.scaled_dot_product_attention(sp(qs, nq) * 0.6931471805599453, sp(k, nk), sp(v, nk), scale=1.0)
+    want = want.transpose(1, 2).reshape(B, nq, C).float()
+    if nsplit > 1:
+        got = ops.attention_split(qs.cuda(), k.cuda(), v.cuda(), heads, nsplit)
+    else:
+        got = ops.attention(qs.cuda(), k.cuda(), v.cuda(), heads, scale=0.0)
+    close(got, want, tol=2 ** -6, what=f"attention, scores jumping at key {jump_at} of {nk}")
+
+
 @pytest.mark.parametrize("B,heads,nq,nk,nsplit,shift", [
     (1, 5, 4096, 4096, 4, 0.0),        # the 64x64-level self-attention of a batch-1 forward
     (1, 10, 1024, 1024, 4, 0.0), (1, 10, 1024, 1024, 2, 0.0),
