@@ -40,6 +40,10 @@ MVD_DEVINL float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __exp
 //   gelu(x) = max(x, 0) - 0.5 |x| P(t) e^{-x^2/2},  t = 1 / (1 + p |x| / sqrt 2),  P = t (a1 + t (a2 + t (a3 + t (a4 + t a5))))
 // (x >= 0: 0.5 x (2 - P e); x < 0: 0.5 x P e): 13 VALU ops + rcp + exp2, no sign transfer -- the GEGLU epilogue is ~30 % of a
 // K = 320 tile of the FF1 GEMM.
+// (-DMVD_GELU_POLY, A/B builds: erf as an odd polynomial -- z = clamp(x, +-4.25), erf(z / sqrt 2) ~ z R(z^2), R of degree 8, no
+//  transcendentals, every operation a v_pk_*_f32 -- half the vector work, |gelu error| <= 5.3e-5 absolute.  Measured: cfg4 cold
+//  63.76 -> 63.53 ms (+0.4 %): the epilogue phase is not bound by its arithmetic alone.  Not worth giving up 1.5e-7; not the default.)
+#ifndef MVD_GELU_POLY
 MVD_DEVINL float gelu_erf_f(float x) {
   const float ax = fabsf(x);
   const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, ax, 1.0f));
@@ -52,6 +56,21 @@ MVD_DEVINL float gelu_erf_f(float x) {
   const float h = (0.5f * ax) * (p * t) * e;
   return fmaxf(x, 0.f) - h;
 }
+#else
+MVD_DEVINL float gelu_erf_f(float x) {
+  const float z = __builtin_amdgcn_fmed3f(x, -4.25f, 4.25f);
+  const float t = z * z;
+  float r = fmaf(1.112984843e-10f, t, -1.065562572e-08f);
+  r = fmaf(r, t, 4.510895621e-07f);
+  r = fmaf(r, t, -1.125293875e-05f);
+  r = fmaf(r, t, 1.868385298e-04f);
+  r = fmaf(r, t, -2.217133064e-03f);
+  r = fmaf(r, t, 1.963203214e-02f);
+  r = fmaf(r, t, -1.326895654e-01f);
+  r = fmaf(r, t, 7.978081107e-01f);
+  return x * fmaf(0.5f * z, r, 0.5f);
+}
+#endif
 
 MVD_DEVINL float wave_sum(float v) {
 #pragma unroll

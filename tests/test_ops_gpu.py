@@ -77,6 +77,33 @@ def test_linear_and_conv_splitk(ops, splitk, cfg):
     close(got, want, what=f"conv splitk={splitk}")
 
 
+@pytest.mark.parametrize("cfg,m", [(-1, 512), (6, 8192)])
+def test_gelu_of_the_geglu_epilogue(ops, cfg, m):
+    """The GEGLU epilogue's erf GELU (common.h: Abramowitz-Stegun 7.1.26, |error| 1.5e-7) swept through a GEMM whose value half
+    is the constant 1 (bias) and whose gate half passes one input column through -- out = gelu(x) -- against fp64
+    0.5 x (1 + erf(x / sqrt 2)) over |x| <= 12, tails and the region around zero included: within half a bf16 ulp of the output
+    (+ 1e-6 absolute)."""
+    from mvd_amd.packing import _geglu_rows
+    k, n_out = 64, 160
+    x = torch.linspace(-12.0, 12.0, m * n_out).view(m, n_out)
+    x = x.to(torch.bfloat16)
+    a = torch.zeros(m, k, dtype=torch.bfloat16)
+    out_all = torch.empty(m, n_out)
+    w = torch.zeros(2 * n_out, k)
+    w[n_out:, 0] = 1.0                                    # gate_j = a[:, 0] for every output column j
+    bias = torch.cat([torch.ones(n_out), torch.zeros(n_out)])
+    wp, bp = _geglu_rows(w).to(torch.bfloat16), _geglu_rows(bias)
+    for j in range(0, n_out, 40):                         # each pass sweeps another slice of the range through column 0
+        a[:, 0] = x[:, j]
+        got = ops.linear(a.cuda(), wp.cuda(), bp.cuda(), geglu=True, force_cfg=cfg).float().cpu()
+        xj = x[:, j].double()
+        want = 0.5 * xj * (1.0 + torch.erf(xj / math.sqrt(2.0)))
+        err = (got[:, 0].double() - want).abs()
+        bound = want.abs() * 2.0 ** -8 + 1e-6
+        assert bool((err <= bound).all()), f"gelu: worst excess {(err - bound).max().item():.3g} at x = {xj[(err - bound).argmax()].item():.4g}"
+        assert torch.equal(got, got[:, :1].expand_as(got)), "all output columns see the same gate"
+
+
 def test_probe_only_configs_are_rejected_and_lockstep_fallback_works(ops):
     """256x160 / 256x128 / 128x320 tiles and the forced lock-step 256x320 forms are not in the product library; the lock-step
     256x320 kernel itself remains as the fallback of the ping-pong kernels (here: an fp32 output, which those do not write)."""
