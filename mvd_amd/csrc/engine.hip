@@ -84,7 +84,15 @@ struct mvd_engine {
   bool dual_now = false;                    // this forward runs the encoder pass on the side stream
   int ensure_side_stream() {
     if (side) return 0;
-    if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) { mvd_set_error("engine: hipStreamCreate failed"); return -3; }
+    {
+      // the side stream gets the HIGHEST priority: the encoder pass is the producer of every adapter attention's K/V, and with it
+      // ahead the main pass fills the gaps (cfg4 cold, same box: default priority 63.06 / 62.83 ms, lowest 62.92 / 62.78, highest
+      // 62.69 / 62.58; batch 1 indifferent; mvd_debug_set_flags bit 64 = default priority, for A/B)
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+      const int pr = (g_debug_flags & 64) ? 0 : hi;
+      if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, pr) != hipSuccess) { mvd_set_error("engine: hipStreamCreate failed"); return -3; }
+    }
     feat_ev.resize(feats.size());
     for (auto& ev : feat_ev) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { mvd_set_error("engine: hipEventCreate failed"); return -3; }
     if (hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&join_ev, hipEventDisableTiming) != hipSuccess) { mvd_set_error("engine: hipEventCreate failed"); return -3; }
