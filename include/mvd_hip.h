@@ -209,7 +209,9 @@ int mvd_gemm_sm_num_tiles(void);
 /* Measurement hook: log2(waves per attention workgroup) for every later launch of this process; -1 = heuristic. */
 int mvd_debug_set_attention_nw(int nw_log2);
 /* Measurement / bisection switches of the engine's schedule: bit 0 no LayerNorm fold through the small-M kernels, bit 1 the
- * small-M kernels never split K, bit 2 small-M kernels off.  0 = the product's behaviour. */
+ * small-M kernels never split K, bit 2 small-M kernels off, bit 3 no split-KV attention, bit 4 the reference-encoder pass on the
+ * caller's stream (one stream), bit 5 the single-stream launch policy (split-K / tile choice) also while two streams run,
+ * bit 6 the side stream at default instead of highest priority (read when the stream is created).  0 = the product's behaviour. */
 int mvd_debug_set_flags(int flags);
 
 /* ---- denoising-loop helpers either side of the UNet, fp32 latents ------ */
