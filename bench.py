@@ -347,7 +347,19 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
         env = dict(os.environ)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        sys.exit(subprocess.run(cmd, env=env).returncode)
+        # the children's stdout is filtered: only a JSON line that carries "metric" is this program's stdout (communication
+        # libraries chat on stdout -- "[Gloo] Rank 0 is connected to ..." in rehearsal mode); everything else goes to stderr
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+        for ln in proc.stdout:
+            is_line = False
+            if ln.lstrip().startswith("{"):
+                try:
+                    is_line = "metric" in json.loads(ln)
+                except ValueError:
+                    pass
+            (sys.stdout if is_line else sys.stderr).write(ln)
+            (sys.stdout if is_line else sys.stderr).flush()
+        sys.exit(proc.wait())
 
     from mvd_amd import distributed as D
     if args.launch_dry_run:
