@@ -165,6 +165,14 @@ int mvd_op_linear(const void* a, const void* a2, int k1, int k2, const void* w, 
  * LayerNorm kernel + mvd_op_linear). */
 int mvd_op_ln_linear(const void* x, int k, const void* w_folded, const float* c1, const float* c2, float eps, int geglu,
                      void* out, int m, int n, void* stream);
+/* The X-stationary short-K form (mvd_amd/csrc/gemm_xs.hip; K = 320, the 64x64 level of SD-2.1 at many rows):
+ *   out[M][units*32] = LN?(x[M][K]) . W^T + b (+ res)        geglu = 1: out[M][units*16] = value * gelu_erf(gate)
+ * x rows stay in registers, w_packed is the fragment-ordered weight stream of mvd_amd/packing.py::pack_xs (bias included;
+ * ln = 1: packed from the LayerNorm-folded pair of fold_layernorm).  csplit <= 0: heuristic column split.
+ * Replaces, for those shapes, the Linear / GEGLU projections of diffusers' BasicTransformerBlock that
+ * /root/reference/src/models/mvd_unet.py:318-326 reaches through UNet2DConditionModel.forward. */
+int mvd_op_linear_xs(const void* x, int ldx, const void* w_packed, int m, int k, int units, int geglu, int ln, float ln_eps,
+                     const void* res, int ldres, void* out, int ldo, int csplit, void* stream);
 /* 3x3 conv (pad 1) on NHWC bf16 as implicit GEMM; optional fused 1x1 shortcut on (sc, sc2).  asym_pad = 1 (stride 2 only):
  * zero padding on the bottom/right edge only -- diffusers' VAE Downsample2D(padding=0). */
 int mvd_op_conv3x3(const void* x, int batch, int in_h, int in_w, int cin, int stride, int upsample, int asym_pad, const void* w,

@@ -21,7 +21,8 @@
 int mvd_launch_silu_to_bf16(const float* x, int64_t n, bf16_t* y, hipStream_t s);
 
 // measurement / bisection switches (bench.py --debug-flags, tools/): bit 0 = no LayerNorm fold through the small-M kernels,
-// bit 1 = small-M kernels never split K, bit 2 = small-M kernels off, bit 3 = no split-KV attention, bit 4 = no side stream
+// bit 1 = small-M kernels never split K, bit 2 = small-M kernels off, bit 3 = no split-KV attention, bit 4 = no side stream,
+// bit 7 (128) = X-stationary kernels off
 static int g_debug_flags = 0;
 extern "C" int mvd_debug_set_flags(int flags) { g_debug_flags = flags; return 0; }
 
@@ -146,7 +147,8 @@ struct mvd_engine {
 // profile class of a GEMM launch = the KERNEL that runs it (each is a distinct rocprof kernel name): tile config for the
 // lock-step kernels of gemm.hip; for the ping-pong kernels of gemm_pp.hip 7 = dense A operand, 13 = implicit-GEMM 3x3
 // convolution (incl. the fused 1x1 shortcut / upsample forms), 14 = their split-K forms, 15 = dense with the LayerNorm fold,
-// 6 = GEGLU (with or without the fold).  (8..11 are attention.)
+// 6 = GEGLU (with or without the fold).  (8..11 are attention.)  30..33 = the X-stationary kernels of gemm_xs.hip (dense, residual,
+// LayerNorm, GEGLU).
 static inline int gemm_class(const MvdGemmArgs& g, int cfg, int splitk) {
   if (cfg == 8) return 12;
   if (cfg == 7) return splitk > 1 ? 14 : (g.seg[0].mode == MVD_A_CONV3 ? 13 : (g.ln_c1 ? 15 : 7));
@@ -252,9 +254,33 @@ struct Ctx {
     return r;
   }
 
-  // dense linear: out[M][N] = alpha*(A.W^T + bias) + res
+  // X-stationary form (gemm_xs.hip) of a K = 320 projection over many rows: taken when the packed twin `<slot>.wx`
+  // (packing.pack_xs: weights in fragment order, bias -- or the LayerNorm-folded c2 -- inside) is registered.  Returns 1 when
+  // it launched, 0 when the caller should go on with the general kernels, < 0 on error.  `n_full`: rows of the packed matrix
+  // (a pass may use a prefix of them: the q/k/v rows without the adapter's q_ref).
+  int try_xs(const bf16_t* x, int K, int M, const std::string& slot, int64_t n_full, int N, bool geglu, bool ln,
+             const bf16_t* res, int ldres, void* out, int ldo, int set_override = -1) {
+    if (err) return err;
+    if (dry || (g_debug_flags & 128) || K != 320 || M < 32768 || slot.empty() || !has(slot, set_override)) return 0;
+    MvdXsArgs a; memset(&a, 0, sizeof(a));
+    a.x = x; a.ldx = K; a.M = M; a.K = K; a.units = N / 32; a.geglu = geglu; a.ln = ln; a.ln_eps = 1e-5f;
+    a.res = res; a.ldres = ldres; a.out = (bf16_t*)out; a.ldo = ldo;
+    if (N % 64 || !mvd_gemm_xs_applicable(a)) return 0;
+    a.w = WB(slot, (n_full / 32) * 21 * 512, set_override);
+    if (!a.w) return err;
+    e->prof_M = M; e->prof_N = N; e->prof_K = K; e->prof_tag = geglu * 10 + (ln ? 1 : 0);
+    const int r = profiled(geglu ? 33 : (res ? 31 : (ln ? 32 : 30)), 2.0 * M * (double)N * K, 0.0, [&] { return mvd_launch_gemm_xs(a, s); });
+    return r ? r : 1;
+  }
+
+  // dense linear: out[M][N] = alpha*(A.W^T + bias) + res       (xs: slot name of the X-stationary twin, if the site has one)
   int linear(const bf16_t* a, const bf16_t* a2, int k1, int k2, int M, const bf16_t* w, const float* bias, int N,
-             const bf16_t* res, int ldres, void* out, int ldo, bool geglu = false, bool out_f32 = false, int ldw = 0) {
+             const bf16_t* res, int ldres, void* out, int ldo, bool geglu = false, bool out_f32 = false, int ldw = 0,
+             const std::string& xs = std::string(), int xs_set = -1) {
+    if (!xs.empty() && !a2 && !k2 && !geglu && !out_f32) {
+      const int r = try_xs(a, k1, M, xs, N, N, false, false, res, ldres, out, ldo, xs_set);
+      if (r) return r < 0 ? r : 0;
+    }
     MvdGemmArgs g; memset(&g, 0, sizeof(g));
     g.ldw = ldw ? ldw : k1 + k2;
     g.seg[0].p0 = a; g.seg[0].p1 = a2; g.seg[0].c0 = k1; g.seg[0].c1 = k2; g.seg[0].mode = MVD_A_DENSE; g.seg[0].ksize = k1 + k2;
@@ -271,6 +297,10 @@ struct Ctx {
     MvdGemmArgs g; memset(&g, 0, sizeof(g));
     g.ldw = C; g.seg[0].p0 = x; g.seg[0].c0 = C; g.seg[0].mode = MVD_A_DENSE; g.seg[0].ksize = C; g.nseg = 1;
     g.M = M; g.N = N; g.Ktot = C; g.rows_per_batch = M; g.outH = 1; g.outW = M; g.alpha = 1.f; g.geglu = geglu; g.out = out; g.ldo = ldo;
+    {
+      const int r = try_xs(x, C, M, slot + ".wx", n_full, N, geglu, true, nullptr, 0, out, ldo);
+      if (r) return r < 0 ? r : 0;
+    }
     static const bool use_fold = MVD_ENV_INT("MVD_LN_FOLD", 1) != 0;
     auto sm_fold_ok = [&]() {      // the small-M kernels (batch 1) fold at every level
       MvdGemmArgs t = g;
@@ -443,7 +473,7 @@ struct UNetPass {
     bf16_t* n0 = c.talloc<bf16_t>((size_t)M * C);
     CHECK(c.groupnorm(x.p, nullptr, C, 0, B_, hw, 1e-6f, c.WF(key + ".norm.g", C), c.WF(key + ".norm.b", C), 0, n0));
     bf16_t* h = c.talloc<bf16_t>((size_t)M * C);
-    CHECK(c.linear(n0, nullptr, C, 0, M, c.WB(key + ".proj_in.w", (int64_t)C * C), c.WF(key + ".proj_in.b", C), C, nullptr, 0, h, C));
+    CHECK(c.linear(n0, nullptr, C, 0, M, c.WB(key + ".proj_in.w", (int64_t)C * C), c.WF(key + ".proj_in.b", C), C, nullptr, 0, h, C, false, false, 0, key + ".proj_in.wx"));
     bf16_t* ln = n0;  // reuse
     const float scale = 0.125f;   // (folded, with log2 e, into the packed to_q / to_q_ref rows: a.prescaled)
     bf16_t* o_self = c.talloc<bf16_t>((size_t)M * C);
@@ -467,7 +497,8 @@ struct UNetPass {
       CHECK(c.attention(a));
       const int kout = ad ? 2 * C : C;
       (void)kout;
-      CHECK(c.linear(o_self, o_ref, C, ad ? C : 0, M, c.WB(key + ".attn1.out.w", (int64_t)C * ld_out), c.WF(key + ".attn1" + bias_slot, C), C, h, C, h, C, false, false, ld_out));
+      CHECK(c.linear(o_self, o_ref, C, ad ? C : 0, M, c.WB(key + ".attn1.out.w", (int64_t)C * ld_out), c.WF(key + ".attn1" + bias_slot, C), C, h, C, h, C, false, false, ld_out,
+                     ad ? std::string() : key + ".attn1.out.wx"));
     }
     // ---- attn2 (text cross) + adapter branch "<feature>_cross"
     {
@@ -483,7 +514,8 @@ struct UNetPass {
       CHECK(c.attention(a));
       const int kout = ad ? 2 * C : C;
       (void)kout;
-      CHECK(c.linear(o_self, o_ref, C, ad ? C : 0, M, c.WB(key + ".attn2.out.w", (int64_t)C * ld_out), c.WF(key + ".attn2" + bias_slot, C), C, h, C, h, C, false, false, ld_out));
+      CHECK(c.linear(o_self, o_ref, C, ad ? C : 0, M, c.WB(key + ".attn2.out.w", (int64_t)C * ld_out), c.WF(key + ".attn2" + bias_slot, C), C, h, C, h, C, false, false, ld_out,
+                     ad ? std::string() : key + ".attn2.out.wx"));
     }
     // ---- GEGLU feed-forward
     {
@@ -491,7 +523,7 @@ struct UNetPass {
       CHECK(c.ln_linear(h, M, C, key + ".ln3", key + ".ff1", (int64_t)8 * C, 8 * C, c.WF(key + ".ff1.b", 8 * C), ln, ff, 4 * C, true));
       CHECK(c.linear(ff, nullptr, 4 * C, 0, M, c.WB(key + ".ff2.w", (int64_t)C * 4 * C), c.WF(key + ".ff2.b", C), C, h, C, h, C));
     }
-    CHECK(c.linear(h, nullptr, C, 0, M, c.WB(key + ".proj_out.w", (int64_t)C * C), c.WF(key + ".proj_out.b", C), C, x.p, C, out.p, C));
+    CHECK(c.linear(h, nullptr, C, 0, M, c.WB(key + ".proj_out.w", (int64_t)C * C), c.WF(key + ".proj_out.b", C), C, x.p, C, out.p, C, false, false, 0, key + ".proj_out.wx"));
     c.e->tmp.off = mark;
 
     if (o.capture) {  // encoder pass: reference normalisation (Q2) + adapter K/V for both processors of this feature
@@ -501,7 +533,8 @@ struct UNetPass {
         if (!c.dry && !c.err) CHECK(mvd_launch_refstats(out.p, B_, hw, C, o.stats + 2 * c.e->feat_pixel_off(feat_idx), c.s));
       } else {
         if (!c.dry && !c.err) CHECK(mvd_launch_refnorm(out.p, B_, hw, C, rn, c.s));
-        CHECK(c.linear(rn, nullptr, C, 0, M, c.WB(key + ".ref_kv.w", (int64_t)4 * C * C, 0), nullptr, 4 * C, nullptr, 0, c.e->refkv[feat_idx], 4 * C));
+        CHECK(c.linear(rn, nullptr, C, 0, M, c.WB(key + ".ref_kv.w", (int64_t)4 * C * C, 0), nullptr, 4 * C, nullptr, 0, c.e->refkv[feat_idx], 4 * C, false, false, 0,
+                       key + ".ref_kv.wx", 0));
         if (c.e->dual_now && !c.dry && !c.err && hipEventRecord(c.e->feat_ev[feat_idx], c.s) != hipSuccess) { mvd_set_error("forward: hipEventRecord failed"); return -3; }
       }
       if (c.e->rc_keep && !c.dry && !c.err)

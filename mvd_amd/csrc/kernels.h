@@ -77,6 +77,22 @@ bool mvd_gemm_sm_applicable(const MvdGemmArgs& a, int tile);
 int mvd_launch_gemm_sm(const MvdGemmArgs& a, hipStream_t s, int tile, int nstage);
 // whether the engine should give this problem to the small-M kernels, and with which tile / ring depth / split-K
 bool mvd_gemm_sm_plan(const MvdGemmArgs& a, int* tile, int* nstage, int* splitk);
+// X-stationary short-K kernels (gemm_xs.hip): the activation rows stay in registers as the MFMA B operand (tokens on lanes), the
+// weights stream through an LDS ring in the fragment-ordered layout of packing.pack_xs -- `units` 32-row tiles of
+// (K / 16 + 1) x 1 KB (the last k-step carries the bias; GEGLU: units alternate gate | value of one 32-channel output tile).
+struct MvdXsArgs {
+  const bf16_t* x; int ldx;     // [M][ldx] bf16, the first K columns are the operand
+  const bf16_t* w;              // packed weights: [units][K / 16 + 1][64][8] bf16
+  int M, K, units;
+  int geglu;                    // 1: out[M][units * 16] = value * gelu_erf(gate)
+  int ln; float ln_eps;         // 1: LayerNorm the rows first (gamma / beta folded into w and its bias k-step: packing.fold_layernorm)
+  const bf16_t* res; int ldres; // residual [M][ldres] bf16 or null (not with geglu)
+  bf16_t* out; int ldo;
+  int csplit;                   // column parts per row block (<= 0: mvd_gemm_xs_pick_csplit)
+};
+bool mvd_gemm_xs_applicable(const MvdXsArgs& a);
+int mvd_gemm_xs_pick_csplit(const MvdXsArgs& a);
+int mvd_launch_gemm_xs(const MvdXsArgs& a, hipStream_t s);
 #define MVD_OP_SPLITK_COUNTERS 4096   // tile counters behind the partials of an mvd_op_linear / mvd_op_conv3x3 split-K workspace
 // sum the split-K partials and apply the GEMM epilogue (bias, row vector, alpha, residual) -> out
 int mvd_launch_splitk_reduce(const MvdGemmArgs& a, hipStream_t s);

@@ -286,7 +286,9 @@ class MVDEngine:
                        16: "groupnorm", 17: "layernorm",
                        # small-M kernels (gemm_sm.hip), by tile
                        20: "gemm_sm_64x64", 21: "gemm_sm_128x64", 22: "gemm_sm_64x128", 23: "gemm_sm_128x128", 24: "gemm_sm_64x160",
-                       25: "gemm_sm_128x160", 26: "gemm_sm_64x320"}
+                       25: "gemm_sm_128x160", 26: "gemm_sm_64x320",
+                       # X-stationary short-K kernels (gemm_xs.hip)
+                       30: "gemm_xs_dense", 31: "gemm_xs_residual", 32: "gemm_xs_ln_dense", 33: "gemm_xs_geglu"}
 
     def set_profiling(self, enable: bool):
         L.call("mvd_engine_set_profiling", self._h, int(enable))

@@ -59,6 +59,22 @@ def ln_linear(x, w_folded, cf, eps=1e-5, geglu=False):
     return out
 
 
+def linear_xs(x, w_packed, geglu=False, ln=False, eps=1e-5, res=None, csplit=0, k=None):
+    """The X-stationary short-K GEMM (gemm_xs.hip): out = LN?(x[:, :k]) @ W.T + b (+ res), or value * gelu(gate).
+    ``w_packed`` from packing.pack_xs (bias inside; ``ln``: packed from the fold_layernorm pair)."""
+    _bf16(x, w_packed, res)
+    m = x.shape[0]
+    units, ks1 = w_packed.shape[0], w_packed.shape[1]
+    k = (ks1 - 1) * 16 if k is None else k
+    n_out = units * 16 if geglu else units * 32
+    out = torch.empty(m, n_out, device=x.device, dtype=torch.bfloat16)
+    assert x.stride(1) == 1 and (res is None or res.stride(1) == 1)
+    L.call("mvd_op_linear_xs", C.c_void_p(x.data_ptr()), x.stride(0), _p(w_packed), m, k, units, int(geglu), int(ln), float(eps),
+           C.c_void_p(res.data_ptr()) if res is not None else None, res.stride(0) if res is not None else 0, _p(out), n_out,
+           csplit, _s())
+    return out
+
+
 def conv3x3(x, w_packed, bias=None, stride=1, upsample=False, rowvec=None, res=None, shortcut=None,
             shortcut2=None, force_cfg=-1, splitk=1, asym_pad=False):
     """x: (B,H,W,Cin) bf16; w_packed: (Cout, 9*Cin [+ Csc]) bf16 tap-major.  asym_pad (stride 2): zero padding on the

@@ -70,6 +70,48 @@ def _geglu_rows(w: torch.Tensor) -> torch.Tensor:
     return torch.cat([v, g], dim=1).reshape(w.shape)
 
 
+XS_K = 320      # operand width of the X-stationary kernels (gemm_xs.hip): the 64x64 level of SD-2.1
+
+
+def _xs_row_perm(device) -> torch.Tensor:
+    """MFMA row m of a 32-row unit -> channel of the unit it must hold so that lane (token, h) ends up with the 16
+    CONSECUTIVE channels 16 h .. 16 h + 15 in its 16 accumulator registers (v_mfma_f32_32x32x16_bf16: register q of half h
+    is row (q & 3) + 8 (q >> 2) + 4 h)."""
+    m = torch.arange(32, device=device)
+    return 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3)
+
+
+def pack_xs(w: torch.Tensor, bias, geglu: bool = False, device=None) -> torch.Tensor:
+    """[N][K] (+ bias [N] or None) -> the weight stream of gemm_xs.hip: ``[units][K/16 + 1][64][8]`` bf16.
+
+    A unit is a 32-row tile in the order the kernel consumes it: k-step ``s < K/16`` is one MFMA A-operand fragment (lane
+    ``(r, h)`` holds ``W[row(r)][16 s + 8 h .. + 8]``, rows permuted by ``_xs_row_perm``), the last k-step carries the bias
+    split into two bf16 (hi at k = 0, lo at k = 1 of half 0) against the kernel's constant 1.0 operand.  ``geglu``: ``w``
+    holds the value rows then the gate rows (diffusers' GEGLU.proj); units alternate gate | value of one 32-channel tile."""
+    device = device if device is not None else w.device
+    w = w.detach().to(device=device, dtype=torch.float32)
+    n, k = w.shape
+    assert k % 16 == 0 and n % (64 if geglu else 32) == 0, (n, k)
+    b = torch.zeros(n, device=device) if bias is None else bias.detach().to(device=device, dtype=torch.float32)
+    if geglu:
+        half = n // 2
+        order = torch.stack([torch.arange(half, n, device=device).reshape(-1, 32),          # gate tile j
+                             torch.arange(0, half, device=device).reshape(-1, 32)], 1).reshape(-1)   # value tile j
+        w, b = w[order], b[order]
+    units, ks = n // 32, k // 16
+    perm = _xs_row_perm(device)
+    wu = w.reshape(units, 32, k)[:, perm]                                   # [unit][m][k]: MFMA row order
+    bu = b.reshape(units, 32)[:, perm]
+    frag = wu.reshape(units, 32, ks, 2, 8).permute(0, 2, 3, 1, 4)           # [unit][s][h][r][8]
+    out = torch.zeros(units, ks + 1, 2, 32, 8, device=device, dtype=torch.bfloat16)
+    out[:, :ks] = frag.to(torch.bfloat16)
+    hi = bu.to(torch.bfloat16)
+    lo = (bu - hi.float()).to(torch.bfloat16)
+    out[:, ks, 0, :, 0] = hi
+    out[:, ks, 0, :, 1] = lo
+    return out.reshape(units, ks + 1, 64, 8).contiguous()
+
+
 # LayerNorm fold: only the 64x64 / 32x32 levels (C = 320 / 640 in SD-2.1) ever reach the fused kernel (it needs >= 200
 # tiles of 256x320, i.e. many rows); deeper levels keep ln_kernel + the plain GEMM and get no folded twin
 LN_FOLD_MAX_C = 1 << 30     # every level: the small-M kernels (batch 1) fold at C = 1280 too (the M = 32-images kernels stop at 640)
@@ -160,6 +202,20 @@ def pack_unet(sd: Dict[str, torch.Tensor], cfg: UNetConfig, device, adapter: boo
             for slot, w, bias, i in ((f"{key}.attn1.qkv", torch.cat(qkv, 0), None, 1), (f"{key}.attn2.q", torch.cat(q2, 0), None, 2),
                                      (f"{key}.ff1", ff1_w, ff1_b, 3)):
                 out[f"{slot}.wf"], out[f"{slot}.cf"] = fold_layernorm(w, f(f"{b}.norm{i}.weight"), f(f"{b}.norm{i}.bias"), bias, device)
+        if C == XS_K:
+            # twins for the X-stationary kernels (gemm_xs.hip): the K = 320 projections of the 64x64 level
+            out[f"{key}.proj_in.wx"] = pack_xs(f(f"{key}.proj_in.weight"), f(f"{key}.proj_in.bias"), device=device)
+            out[f"{key}.proj_out.wx"] = pack_xs(f(f"{key}.proj_out.weight"), f(f"{key}.proj_out.bias"), device=device)
+            for a in ("attn1", "attn2"):   # the out-projection of a pass WITHOUT the adapter branch (K = C)
+                out[f"{key}.{a}.out.wx"] = pack_xs(f(f"{b}.{a}.to_out.0.weight"), f(f"{b}.{a}.to_out.0.bias"), device=device)
+            if adapter:
+                out[f"{key}.ref_kv.wx"] = pack_xs(out[f"{key}.ref_kv.w"].float(), None, device=device)
+            for slot, geglu in ((f"{key}.attn1.qkv", False), (f"{key}.attn2.q", False), (f"{key}.ff1", True)):
+                wf, cf = out[f"{slot}.wf"].float(), out[f"{slot}.cf"]
+                if geglu:    # .wf / .cf are in the 16 | 16 interleaved row order of the ping-pong kernel: undo it
+                    inv = torch.argsort(_geglu_rows(torch.arange(wf.shape[0], device=wf.device)))
+                    wf, cf = wf[inv], cf[:, inv]
+                out[f"{slot}.wx"] = pack_xs(wf, cf[1], geglu=geglu, device=device)
         out[f"{key}.ff2.w"] = _bf(sd[f"{b}.ff.net.2.weight"], device)
         out[f"{key}.ff2.b"] = _f32(sd[f"{b}.ff.net.2.bias"], device)
 

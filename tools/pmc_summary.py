@@ -12,6 +12,8 @@ CLASSES = {
     "gemm_sm_64x64": "gemm_sm_kernel<64, 64,", "gemm_sm_128x64": "gemm_sm_kernel<128, 64,", "gemm_sm_64x128": "gemm_sm_kernel<64, 128,",
     "gemm_sm_128x128": "gemm_sm_kernel<128, 128,", "gemm_sm_64x160": "gemm_sm_kernel<64, 160,", "gemm_sm_128x160": "gemm_sm_kernel<128, 160,",
     "gemm_sm_64x320": "gemm_sm_kernel<64, 320,",
+    "gemm_xs_dense": "gemm_xs_kernel<20, false, false, false>", "gemm_xs_residual": "gemm_xs_kernel<20, false, true, false>",
+    "gemm_xs_ln_dense": "gemm_xs_kernel<20, false, false, true>", "gemm_xs_geglu": "gemm_xs_kernel<20, true, false,",
     "gemm_128x160": "Cfg<128, 160, 2, 2>",
     "gemm_128x128": "Cfg<128, 128, 2, 2>", "gemm_128x64": "Cfg<128, 64, 2, 2>", "gemm_64x64": "Cfg<64, 64, 2, 2>",
     "attn_4wave": "attn_kernel<4,", "attn_8wave": "attn_kernel<8,", "attn_2wave": "attn_kernel<2,", "attn_1wave": "attn_kernel<1,",
