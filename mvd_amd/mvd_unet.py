@@ -38,6 +38,7 @@ def _build_unet(cfg: UNetConfig, init: str) -> UNet2DConditionParams:
 
 
 def _resolve_config(path, unet_config: Optional[UNetConfig]) -> UNetConfig:
+    """``path``: a snapshot DIRECTORY (already resolved by hub.resolve_snapshot) or None."""
     if unet_config is not None:
         return unet_config
     if path and os.path.isdir(str(path)):
@@ -70,17 +71,27 @@ def _load_local_unet_weights(module: nn.Module, path) -> bool:
     return True
 
 
+def _load_named_unet(module: nn.Module, name, snapshot, what: str):
+    """A NAMED model must bring its weights (the reference's from_pretrained would): no silent random initialisation."""
+    if name is None:
+        return
+    if not _load_local_unet_weights(module, snapshot):
+        raise L.MvdError(f"{what}: {name!r} resolved to {snapshot!r}, which has no unet/diffusion_pytorch_model.safetensors")
+
+
 class ImageEncoder(nn.Module):
     """Mirror of /root/reference/src/models/image_encoder.py: frozen UNet copy whose 16
     Transformer2DModel outputs are the reference features."""
 
     def __init__(self, pretrained_model_name_or_path, dtype: torch.dtype = torch.float32,
-                 expected_sample_size: int = None, unet_config: Optional[UNetConfig] = None, init: str = "default"):
+                 expected_sample_size: int = None, unet_config: Optional[UNetConfig] = None, init: str = "default",
+                 cache_dir=None):
         super().__init__()
-        cfg = _resolve_config(pretrained_model_name_or_path, unet_config)
+        from .hub import resolve_snapshot
+        snapshot = resolve_snapshot(pretrained_model_name_or_path, cache_dir)      # raises for a name nothing local answers to
+        cfg = _resolve_config(snapshot, unet_config)
         self.unet = _build_unet(cfg, init)
-        if not _load_local_unet_weights(self.unet, pretrained_model_name_or_path) and init == "default":
-            logger.warning("ImageEncoder: no local weights for %r -- randomly initialised", pretrained_model_name_or_path)
+        _load_named_unet(self.unet, pretrained_model_name_or_path, snapshot, "ImageEncoder")
         self.unet.config.sample_size = expected_sample_size
         for p in self.unet.parameters():
             p.requires_grad = False
@@ -111,7 +122,7 @@ class MultiViewUNet(nn.Module):
                  img_ref_scale: float = 0.3, cam_modulation_strength: float = 0.2, cam_output_dim: int = 1024,
                  cam_hidden_dim: int = 512, use_camera_conditioning: bool = True, use_image_conditioning: bool = True,
                  simple_cam_encoder: bool = False, *, unet_config: Optional[UNetConfig] = None, init: str = "default",
-                 cache_reference: bool = False, dedup_encoder_weights="auto"):
+                 cache_reference: bool = False, dedup_encoder_weights="auto", cache_dir=None):
         super().__init__()
         self.use_camera_conditioning = use_camera_conditioning
         self.use_image_conditioning = use_image_conditioning
@@ -127,12 +138,15 @@ class MultiViewUNet(nn.Module):
         self.dedup_encoder_weights = dedup_encoder_weights
         self.encoder_weights_shared = False
 
-        cfg = _resolve_config(pretrained_model_name_or_path, unet_config)
+        # mvd_unet.py:46-52: UNet2DConditionModel.from_pretrained(name, subfolder="unet").  Here: a snapshot directory or a
+        # hub name already in a local huggingface cache (hub.resolve_snapshot); a name nothing local answers to RAISES
+        from .hub import resolve_snapshot
+        snapshot = resolve_snapshot(pretrained_model_name_or_path, cache_dir)
+        self.pretrained_snapshot = snapshot
+        cfg = _resolve_config(snapshot, unet_config)
         self.unet_config = cfg
         self.base_unet = _build_unet(cfg, init)
-        if not _load_local_unet_weights(self.base_unet, pretrained_model_name_or_path) and init == "default":
-            logger.warning("MultiViewUNet: no local weights for %r -- randomly initialised "
-                           "(no network / hub access in this build)", pretrained_model_name_or_path)
+        _load_named_unet(self.base_unet, pretrained_model_name_or_path, snapshot, "MultiViewUNet")
         self.config = self.base_unet.config
         self.device = torch.device("cpu")
         self.dtype = dtype
@@ -146,7 +160,7 @@ class MultiViewUNet(nn.Module):
         else:
             self.camera_encoder = None
         if use_image_conditioning:
-            self.image_encoder = ImageEncoder(pretrained_model_name_or_path, dtype=dtype,
+            self.image_encoder = ImageEncoder(snapshot, dtype=dtype,
                                               expected_sample_size=self.config.sample_size, unet_config=cfg, init=init)
             self.image_encoder._encode_fn = self._encode_reference
         else:

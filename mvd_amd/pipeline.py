@@ -23,6 +23,8 @@ import os
 from types import SimpleNamespace
 from typing import Any, Callable, Dict, List, Optional, Union
 
+import logging
+
 import torch
 
 from . import _lib as L
@@ -77,6 +79,9 @@ class MVDDenoiser:
             if callback is not None and i % callback_steps == 0:                # pipeline.py:165-166
                 callback(i, t, latents)
         return latents
+
+
+logger = logging.getLogger(__name__)
 
 
 class MVDPipeline:
@@ -221,14 +226,18 @@ def _optional_components(path, dtype):
             vae = AutoencoderKLHIP.from_snapshot(os.path.join(str(path), "vae"))
         except Exception as e:   # a snapshot that is there but does not load is an error, not "no VAE"
             raise L.MvdError(f"VAE snapshot under {os.path.join(str(path), 'vae')} failed to load: {type(e).__name__}: {e}") from e
-    try:
-        from transformers import CLIPTextModel, CLIPTokenizer
-        if os.path.isdir(os.path.join(str(path), "text_encoder")) and os.path.isdir(os.path.join(str(path), "tokenizer")):
-            tokenizer = CLIPTokenizer.from_pretrained(os.path.join(str(path), "tokenizer"), local_files_only=True)
-            text_encoder = CLIPTextModel.from_pretrained(os.path.join(str(path), "text_encoder"), local_files_only=True,
-                                                         torch_dtype=dtype)
-    except Exception:   # no weights / no library: the caller passes prompt_embeds
-        tokenizer = text_encoder = None
+    te_dir, tok_dir = os.path.join(str(path), "text_encoder"), os.path.join(str(path), "tokenizer")
+    if os.path.isdir(te_dir) and os.path.isdir(tok_dir):
+        try:
+            from transformers import CLIPTextModel, CLIPTokenizer
+        except ImportError:     # no library: the caller passes prompt_embeds (the pipeline says so when asked for a prompt)
+            logger.warning("snapshot %s has a text encoder but `transformers` is not importable: pass prompt_embeds", path)
+            return vae, None, None
+        try:
+            tokenizer = CLIPTokenizer.from_pretrained(tok_dir, local_files_only=True)
+            text_encoder = CLIPTextModel.from_pretrained(te_dir, local_files_only=True, torch_dtype=dtype)
+        except Exception as e:   # files that are there but do not load are an error, not "no text encoder"
+            raise L.MvdError(f"text encoder / tokenizer under {path} failed to load: {type(e).__name__}: {e}") from e
     return vae, text_encoder, tokenizer
 
 
@@ -236,10 +245,14 @@ def build_pipeline(pretrained_model_name_or_path, dtype, use_camera_conditioning
                    cam_modulation_strength, cam_output_dim, cam_hidden_dim, simple_cam_encoder, cache_dir=None,
                    unet_config=None, init: str = "default") -> MVDPipeline:
     """``create_mvd_pipeline`` (mvd_unet.py:388-453): scheduler swap to the interpolated SNR shift (scale 6, hard-coded
-    there, :420-428), ``MultiViewUNet`` as ``pipeline.unet``, the three attributes of :449-451.  Local snapshot files are
-    used when present; nothing is fetched."""
+    there, :420-428), ``MultiViewUNet`` as ``pipeline.unet``, the three attributes of :449-451.  Nothing is fetched: the
+    name resolves to local snapshot files (hub.resolve_snapshot) or the call raises."""
+    from .hub import resolve_snapshot
     from .mvd_unet import MultiViewUNet
     from .scheduler import DDPMScheduler, ShiftSNRScheduler
+    # MVDPipeline.from_pretrained(name, cache_dir=...) (mvd_unet.py:411-415): a directory, or a hub name whose snapshot is in a
+    # local huggingface cache; a name nothing local answers to raises MvdError (never a random-initialised pipeline)
+    pretrained_model_name_or_path = resolve_snapshot(pretrained_model_name_or_path, cache_dir)
     base_scheduler = _scheduler_from_snapshot(pretrained_model_name_or_path)
     scheduler = ShiftSNRScheduler.from_scheduler(noise_scheduler=base_scheduler, shift_mode="interpolated", shift_scale=6.0,
                                                  scheduler_class=DDPMScheduler)
@@ -251,7 +264,9 @@ def build_pipeline(pretrained_model_name_or_path, dtype, use_camera_conditioning
     if torch.cuda.is_available():
         unet = unet.to(device="cuda", dtype=dtype)
     vae, text_encoder, tokenizer = _optional_components(pretrained_model_name_or_path, dtype)
-    pipe = MVDPipeline(unet, scheduler, vae=vae, text_encoder=text_encoder, tokenizer=tokenizer)
+    # (StableDiffusionPipeline.__init__: vae_scale_factor = 2 ** (len(vae.config.block_out_channels) - 1))
+    vsf = 2 ** (len(vae.config.block_out_channels) - 1) if vae is not None else 8
+    pipe = MVDPipeline(unet, scheduler, vae=vae, text_encoder=text_encoder, tokenizer=tokenizer, vae_scale_factor=vsf)
     pipe.use_camera_conditioning = use_camera_conditioning
     pipe.use_image_conditioning = use_image_conditioning
     pipe.img_ref_scale = img_ref_scale

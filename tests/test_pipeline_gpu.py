@@ -256,3 +256,65 @@ def test_hip_graph_replay_is_bit_exact(tiny):
         model.use_hip_graph = False
         model.cache_reference = False
         model.reset_reference_cache()
+
+
+def test_infer_py_call_sequence_from_cached_hub_name(tmp_path, shim_path):
+    """a17 + N1 end to end: the call sequence of infer.py:33-122 through the integration/ shims with a hub NAME whose
+    snapshot sits in a (fake, tiny) huggingface cache -- pipeline from the name + cache_dir, checkpoint key rewriting,
+    .to(device), the eval() calls, create_camera_matrix, then pipeline(prompt=..., source_images=..., output_type="pt")
+    with the snapshot's own CLIP text encoder and VAE.  The denoising loop itself is checked against the oracle above; here
+    the result must be finite, of the image shape, reproducible, and sensitive to the checkpoint that was loaded."""
+    pytest.importorskip("transformers")
+    from src.models.mvd_unet import create_mvd_pipeline                          # infer.py:1
+    from src.utils import create_camera_matrix                                  # infer.py:3
+    from tests.hub_fixture import REPO, build_fake_hf_cache
+    cache, snap, sds = build_fake_hf_cache(str(tmp_path))
+    device = torch.device("cuda")
+
+    def build(perturb):
+        pipeline = create_mvd_pipeline(pretrained_model_name_or_path=REPO, use_memory_efficient_attention=True,
+                                       enable_gradient_checkpointing=False, dtype=torch.float32, use_camera_conditioning=True,
+                                       use_image_conditioning=True, simple_cam_encoder=False, cache_dir=str(tmp_path),
+                                       cam_output_dim=96, cam_hidden_dim=48)
+        # infer.py:46-69: a Lightning checkpoint ("unet." prefix; old files name the encoder "image_encoder.<key>")
+        g = torch.Generator().manual_seed(3)
+        ckpt = {}
+        for k, v in pipeline.unet.state_dict().items():
+            w = v.clone()
+            if perturb and k.endswith("proj_in.weight"):
+                w = w + 0.5 * torch.randn(w.shape, generator=g)
+            ck = k.replace("image_encoder.unet.", "image_encoder.", 1) if k.startswith("image_encoder.unet.") else k
+            ckpt["unet." + ck] = w
+        unet_keys = {k: v for k, v in ckpt.items() if k.startswith("unet.")}
+        sd = {k.replace("unet.", "", 1): v for k, v in unet_keys.items()}
+        fixed = {}
+        for key, value in sd.items():
+            nk = key
+            if key.startswith("image_encoder.") and not key.startswith("image_encoder.unet."):
+                nk = "image_encoder.unet." + key.split(".", 1)[1]
+            fixed[nk] = value
+        missing, unexpected = pipeline.unet.load_state_dict(fixed, strict=False)
+        assert not missing and not unexpected
+        pipeline = pipeline.to(device)
+        pipeline.unet.eval(); pipeline.vae.eval(); pipeline.text_encoder.eval()
+        pipeline.unet.image_encoder.eval(); pipeline.unet.camera_encoder.eval()
+        return pipeline
+
+    src = create_camera_matrix([0, 0, 2.0], [0, 0, 0]).unsqueeze(0).to(device)
+    tgt = create_camera_matrix([1.5, 0, 1.5], [0, 0, 0]).unsqueeze(0).to(device)
+    image = torch.rand(1, 3, 32, 32, generator=torch.Generator().manual_seed(1)).to(device)      # load_image's [0, 1] tensor
+
+    def run(pipeline):
+        torch.manual_seed(11)                      # (Q1's projection and the ancestral noise come from torch's global RNG)
+        with torch.no_grad():
+            out = pipeline(prompt="a photo of a red chair", num_inference_steps=3, source_camera=src, target_camera=tgt,
+                           source_images=image, guidance_scale=1.0, ref_scale=0.1, output_type="pt",
+                           generator=torch.Generator(device="cuda").manual_seed(5))
+        return out["images"]
+
+    p0 = build(False)
+    a, b = run(p0), run(p0)
+    assert a.shape == (1, 3, 32, 32) and torch.isfinite(a).all() and float(a.min()) >= 0 and float(a.max()) <= 1
+    assert torch.equal(a, b)
+    c = run(build(True))
+    assert not torch.allclose(a, c)                # the loaded checkpoint, not the snapshot's base weights, produced the image
