@@ -43,7 +43,7 @@ def build_fake_hf_cache(root: str, with_text_encoder: bool = True, with_vae: boo
     if with_vae:
         from mvd_amd.vae import AutoencoderKLHIP, VAEConfig
         os.makedirs(os.path.join(snap, "vae"))
-        vc = dict(in_channels=3, latent_channels=4, block_out_channels=[32, 64], layers_per_block=1, norm_num_groups=8,
+        vc = dict(in_channels=3, latent_channels=4, block_out_channels=[64, 128], layers_per_block=1, norm_num_groups=32,
                   scaling_factor=0.18215)
         json.dump({"_class_name": "AutoencoderKL", **vc}, open(os.path.join(snap, "vae", "config.json"), "w"))
         vae = AutoencoderKLHIP(VAEConfig(**vc))

@@ -280,7 +280,7 @@ def test_infer_py_call_sequence_from_cached_hub_name(tmp_path, shim_path):
         g = torch.Generator().manual_seed(3)
         ckpt = {}
         for k, v in pipeline.unet.state_dict().items():
-            w = v.clone()
+            w = v.detach().cpu().clone()                     # (torch.load(..., map_location="cpu"), infer.py:46)
             if perturb and k.endswith("proj_in.weight"):
                 w = w + 0.5 * torch.randn(w.shape, generator=g)
             ck = k.replace("image_encoder.unet.", "image_encoder.", 1) if k.startswith("image_encoder.unet.") else k
