@@ -295,6 +295,7 @@ def launch_dry_run(args, D):
     mine = ref if rank == 0 else {k: torch.zeros_like(v) for k, v in ref.items()}
     arenas, views = D.pack_into_arenas(mine)
     bc = D.broadcast_arenas(arenas.values(), 0)
+    idents = D.gather_identities(int(os.environ.get("LOCAL_RANK", "0")))
     ok = all(torch.equal(views[k], ref[k]) for k in ref)
     D.barrier()
     t0 = time.perf_counter()
@@ -304,7 +305,9 @@ def launch_dry_run(args, D):
     if rank == 0:
         print(json.dumps({"metric": "launch dry run (no GPU work)", "value": 0.0, "unit": "forward-passes/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3, 3),
-                          "weight_broadcast": {"bytes": bc["bytes"], "seconds": round(bc["seconds"], 4), "buckets": bc["buckets"]},
+                          "weight_broadcast": {"bytes": bc["bytes"], "seconds": round(bc["seconds"], 4), "buckets": bc["buckets"],
+                                               "backend": D.collective_library(), "rehearsal": True},
+                          "ranks_seen": idents, "distinct_gpus": D.distinct_devices(idents),
                           "broadcast_ok": bool(ok), "dry_run": True}), flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
@@ -368,6 +371,7 @@ def main():
     # (weight broadcast, barriers, max over ranks); the numbers of such a run mean nothing
     rehearsal = os.environ.get("MVD_BENCH_REHEARSAL") == "1"
     # (init_from_env selects cuda:LOCAL_RANK before the RCCL process group is created)
+    D.check_enough_devices(int(os.environ.get("WORLD_SIZE", "1")), rehearsal)     # before any process group exists
     rank, world, local = D.init_from_env("gloo" if rehearsal else "nccl")
     if rehearsal:
         local = 0
@@ -405,6 +409,7 @@ def main():
         model.mark_weights_changed()
     eng = model._sync_engine()
     bc = D.broadcast_engine_weights(eng, 0)
+    idents = D.gather_identities(local)                 # every rank's GPU, for rank 0's line
     weight_bytes = eng.weight_bytes()
     for p in model.parameters():           # fp32 masters are no longer needed on the device
         p.data = torch.empty(0, device=dev)
@@ -470,6 +475,15 @@ def main():
                 f.write(f"# {args.workload} {'cached' if args.cached else 'cold'} pairs={pairs}, {nprof} profiled steps, kernel_src_sha={kernel_source_sha()}\n")
                 f.write(eng.profile_shapes())
         classes = eng.profile_summary()
+        # the same launches measured INSIDE the forward's own schedule (encoder pass on the side stream): what a rocprofv3
+        # --kernel-trace of the timed region averages, and what the overlapped step time is made of
+        overl = {}
+        if use_img and not args.cached and not args.graph and not (args.debug_flags & 16):
+            eng.set_profiling(2)
+            for _ in range(nprof):
+                step()
+            torch.cuda.synchronize()
+            overl = eng.profile_summary()
         eng.set_profiling(False)
         tot_ms = sum(c["ms"] for c in classes.values())
         mf = {k: c for k, c in classes.items() if c["flops"] > 0}
@@ -495,15 +509,20 @@ def main():
                         "unit": "TFLOP/s", "frac": round(ach * 1e12 / PEAK_BF16_MFMA, 4), "traffic": traffic,
                         "traffic_source": f"{traffic_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same kernel sources)" if traffic else None,
                         "flops_per_launch": round(c["flops"] / c["launches"]),
-                        "avg_launch_us": round(c["ms"] * 1e3 / c["launches"], 2), "launches_per_step": c["launches"] // nprof,
+                        "avg_launch_us": round(c["ms"] * 1e3 / c["launches"], 2),
+                        "avg_launch_us_overlapped": round(overl[dom]["ms"] * 1e3 / overl[dom]["launches"], 2) if dom in overl else None,
+                        "frac_overlapped": round(overl[dom]["flops"] / (overl[dom]["ms"] * 1e-3) / PEAK_BF16_MFMA, 4) if dom in overl else None,
+                        "launches_per_step": c["launches"] // nprof,
                         "share_of_step_time": round(c["ms"] / tot_ms, 3),
-                        "measured_over": f"{nprof} profiled steps after the timed region (HIP events on the launch stream)",
+                        "measured_over": f"{nprof} profiled steps after the timed region (HIP events on the launch stream): avg_launch_us / achieved / frac "
+                                         "with the launches back to back on ONE stream, *_overlapped with the forward's own two-stream schedule",
                         "whole_forward_achieved": round(total_pairs * args.steps * flops_pair / elapsed / world / 1e12, 2),
                         "whole_forward_frac": round(total_pairs * args.steps * flops_pair / elapsed / world / PEAK_BF16_MFMA, 4)}
             for k in classes:
                 classes[k] = {"launches": classes[k]["launches"] // nprof, "ms_per_step": round(classes[k]["ms"] / nprof, 3),
                               "tflops": round(classes[k]["flops"] / max(classes[k]["ms"], 1e-9) / 1e9, 1) if classes[k]["flops"] else None,
-                              "gbps": round(classes[k]["bytes"] / max(classes[k]["ms"], 1e-9) / 1e6, 1) if classes[k]["bytes"] else None}
+                              "gbps": round(classes[k]["bytes"] / max(classes[k]["ms"], 1e-9) / 1e6, 1) if classes[k]["bytes"] else None,
+                              "ms_per_step_overlapped": round(overl[k]["ms"] / nprof, 3) if k in overl else None}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -522,7 +541,9 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "output_check": check, "kernel_src_sha": kernel_source_sha(),
             "gpu_ms_per_step_events": round(gpu_ms / args.steps, 3),
             "weight_bytes_bf16_packed": weight_bytes,
-            "weight_broadcast": {"bytes": bc["bytes"], "seconds": round(bc["seconds"], 4), "buckets": bc["buckets"]},
+            "weight_broadcast": {"bytes": bc["bytes"], "seconds": round(bc["seconds"], 4), "buckets": bc["buckets"],
+                                 "backend": D.collective_library(), "rehearsal": rehearsal},
+            "ranks_seen": idents, "distinct_gpus": D.distinct_devices(idents),
             "kernel_classes": classes,
         }
         print(json.dumps(line), flush=True)

@@ -219,3 +219,66 @@ def max_over_ranks(value: float, device) -> float:
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
+
+
+def collective_library() -> str:
+    """Name + version of the collective library behind the process group (what carried the weight broadcast): "rccl 2.x.y"
+    for backend nccl on ROCm (torch.cuda.nccl.version() IS RCCL's there), "gloo" for the CPU rehearsal backend."""
+    if not dist.is_initialized():
+        return "none"
+    be = dist.get_backend()
+    if be != "nccl":
+        return str(be)
+    try:
+        v = torch.cuda.nccl.version()
+        v = ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception:           # pragma: no cover  (a build without the binding)
+        v = "?"
+    return ("rccl " if getattr(torch.version, "hip", None) else "nccl ") + v
+
+
+def device_identity(local_rank: int) -> Dict[str, object]:
+    """What distinguishes this rank's GPU from the others' on one node: LOCAL_RANK, the device index it bound, and the
+    device's UUID / PCI bus id where the runtime exposes them (a CPU-only rehearsal reports the process id instead)."""
+    ident: Dict[str, object] = {"local_rank": int(local_rank), "pid": os.getpid()}
+    if torch.cuda.is_available():
+        idx = torch.cuda.current_device()
+        ident["device"] = idx
+        try:
+            p = torch.cuda.get_device_properties(idx)
+            ident["name"] = p.name
+            for key in ("uuid", "pci_bus_id", "pci_device_id"):
+                if hasattr(p, key):
+                    ident[key] = str(getattr(p, key))
+        except Exception:       # pragma: no cover
+            pass
+    return ident
+
+
+def gather_identities(local_rank: int) -> List[Dict[str, object]]:
+    """Every rank's ``device_identity`` (one all_gather_object; world size 1: a one-element list).  Rank 0 prints it as
+    ``ranks_seen`` so that whoever launched N ranks can check that N DISTINCT GPUs took part."""
+    me = device_identity(local_rank)
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [me]
+    out: List[object] = [None] * dist.get_world_size()
+    dist.all_gather_object(out, me)
+    return out       # type: ignore[return-value]
+
+
+def distinct_devices(idents: Sequence[Dict[str, object]]) -> int:
+    """Number of different GPUs among the gathered identities (by UUID, else PCI bus id, else device index)."""
+    keys = []
+    for d in idents:
+        keys.append(d.get("uuid") or d.get("pci_bus_id") or ("dev", d.get("device", d.get("pid"))))
+    return len(set(keys))
+
+
+def check_enough_devices(world: int, rehearsal: bool = False):
+    """One rank per GPU: refuse to start more ranks than the node has devices (unless rehearsing on one GPU)."""
+    if rehearsal or not torch.cuda.is_available():
+        return
+    n = torch.cuda.device_count()
+    if n < world:
+        raise RuntimeError(f"WORLD_SIZE={world} ranks but only {n} GPU(s) visible: one process per GPU is the contract "
+                           "(set MVD_BENCH_REHEARSAL=1 for a one-GPU rehearsal of the control flow over gloo)")

@@ -290,7 +290,9 @@ class MVDEngine:
                        # X-stationary short-K kernels (gemm_xs.hip)
                        30: "gemm_xs_dense", 31: "gemm_xs_residual", 32: "gemm_xs_ln_dense", 33: "gemm_xs_geglu"}
 
-    def set_profiling(self, enable: bool):
+    def set_profiling(self, enable):
+        """False / 0: off.  True / 1: per-launch HIP events on ONE stream (serial kernel times).  2: per-launch events with the
+        forward's own two-stream schedule kept (durations while the two passes share the chip)."""
         L.call("mvd_engine_set_profiling", self._h, int(enable))
 
     def profile_shapes(self) -> str:

@@ -25,6 +25,23 @@ def test_bench_gpus2_starts_two_ranks_itself():
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1
     assert line["weight_broadcast"]["bytes"] > 0 and line["broadcast_ok"] is True
     assert line["ms_per_step"] >= 20.0        # the max over ranks (rank 1 sleeps 20 ms), not rank 0's own 10 ms
+    # round 4: who took part.  Two ranks = two processes with their LOCAL_RANKs; the collective library is named
+    assert line["weight_broadcast"]["backend"] == "gloo" and line["weight_broadcast"]["rehearsal"] is True
+    seen = line["ranks_seen"]
+    assert [d["local_rank"] for d in seen] == [0, 1] and len({d["pid"] for d in seen}) == 2
+    assert line["distinct_gpus"] == 2         # (no GPU here: distinct processes stand in for distinct devices)
+
+
+def test_device_identity_helpers():
+    from mvd_amd import distributed as D
+    assert D.collective_library() == "none"                         # no process group in this process
+    assert D.gather_identities(3)[0]["local_rank"] == 3
+    same = [{"local_rank": 0, "uuid": "GPU-a", "device": 0}, {"local_rank": 1, "uuid": "GPU-a", "device": 0}]
+    two = [{"local_rank": 0, "uuid": "GPU-a", "device": 0}, {"local_rank": 1, "uuid": "GPU-b", "device": 1}]
+    assert D.distinct_devices(same) == 1 and D.distinct_devices(two) == 2
+    assert D.distinct_devices([{"device": 0}, {"device": 1}, {"device": 1}]) == 2
+    D.check_enough_devices(8, rehearsal=True)                        # a rehearsal may oversubscribe one GPU
+    D.check_enough_devices(8)                                        # no GPU visible: nothing to check (CPU control-flow tests)
 
 
 def test_bench_flop_counter_reproduces_survey_figures():

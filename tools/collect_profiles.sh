@@ -5,7 +5,7 @@
 # the cfg4 and cfg2 commands, two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) summarised by tools/pmc_summary.py, one
 # GRBM_GUI_ACTIVE pass (shader clock under load, tools/clock_summary.py) and the SQ-counter passes on isolated launches.
 set -e -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -22,9 +22,21 @@ rm -rf $OUT/pmc_clk
 echo "--- cfg4 (the headline configuration, with the CPU baseline)"
 python bench.py --steps 20 --warmup 5 --shapes-out $OUT/shapes_cfg4.txt > $OUT/bench_cfg4.json 2> $OUT/bench_cfg4.err
 cat $OUT/bench_cfg4.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof4 -o stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-check > $OUT/bench_cfg4_under_rocprof.json 2> $OUT/rocprof4.err
-cp $(find $OUT/prof4 -name '*kernel_stats.csv' | head -1) $OUT/bench_cfg4_kernel_stats.csv
+# rocprofv3 kernel stats of the SAME command in its two launch schedules, each pure (--no-profile --no-check: every forward under the
+# profiler is a timed-region forward): two streams (the default; compare with roofline.avg_launch_us_overlapped) and one stream
+# (--debug-flags 16; compare with roofline.avg_launch_us) -- tools/frac_from_stats.py recomputes frac from either
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof4 -o stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-check --no-profile > $OUT/bench_cfg4_under_rocprof_two_streams.json 2> $OUT/rocprof4.err
+cp $(find $OUT/prof4 -name '*kernel_stats.csv' | head -1) $OUT/bench_cfg4_kernel_stats_two_streams.csv
 rm -rf $OUT/prof4
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof4 -o stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-check --no-profile --debug-flags 16 > $OUT/bench_cfg4_under_rocprof_one_stream.json 2> $OUT/rocprof4b.err
+cp $(find $OUT/prof4 -name '*kernel_stats.csv' | head -1) $OUT/bench_cfg4_kernel_stats_one_stream.csv
+rm -rf $OUT/prof4
+python tools/frac_from_stats.py $OUT/bench_cfg4_kernel_stats_two_streams.csv $OUT/bench_cfg4.json two > $OUT/frac_from_stats.txt
+python tools/frac_from_stats.py $OUT/bench_cfg4_kernel_stats_one_stream.csv $OUT/bench_cfg4.json one >> $OUT/frac_from_stats.txt
+cat $OUT/frac_from_stats.txt
+echo "--- sustained: 400 steps"
+python bench.py --steps 400 --warmup 5 --no-cpu-baseline > $OUT/bench_cfg4_400steps.json 2> /dev/null
+python -c "import json;a=json.load(open('$OUT/bench_cfg4.json'));b=json.load(open('$OUT/bench_cfg4_400steps.json'));print('20 steps', a['value'], '400 steps', b['value'], 'ratio', round(b['value']/a['value'],4))" | tee $OUT/sustained.txt
 echo "--- batch 1"
 python bench.py --workload cfg2 --steps 50 --warmup 5 --no-cpu-baseline --shapes-out $OUT/shapes_cfg2.txt > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof2 -o stats -- python3 bench.py --workload cfg2 --steps 25 --warmup 1 --no-cpu-baseline --no-check --no-profile > $OUT/bench_cfg2_under_rocprof.json 2> $OUT/rocprof2.err
