@@ -38,7 +38,8 @@ def ddpm_step(model_out, t, sample, alphas_cumprod, num_train, n_steps, predicti
 
 
 def denoise_loop(params, cfg, betas, prompt, negative, latents, src_cam, tgt_cam, src_lat, n_steps, guidance_scale,
-                 noises, fourier_projs, prediction_type="v_prediction", **mv_kwargs):
+                 noises, fourier_projs, prediction_type="v_prediction", trace=None, **mv_kwargs):
+    """``trace``: a list that receives the latents after every step (drift tests compare whole trajectories)."""
     acp = torch.cumprod(1.0 - betas, dim=0)
     T = betas.shape[0]
     use_cfg = guidance_scale > 1.0 and negative is not None
@@ -51,4 +52,6 @@ def denoise_loop(params, cfg, betas, prompt, negative, latents, src_cam, tgt_cam
             u, c = out.chunk(2)
             out = u + guidance_scale * (c - u)
         latents = ddpm_step(out, t, latents, acp, T, n_steps, prediction_type, noises[i])
+        if trace is not None:
+            trace.append(latents.clone())
     return latents
