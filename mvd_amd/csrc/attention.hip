@@ -539,696 +539,16 @@ __global__ __launch_bounds__(64 * NW, SPLIT ? 3 : (VSUM ? 4 : ((NW == 4 && NSUB 
   }
 }
 
-#ifdef MVD_PROBE   // measurement-only kernels from here to the matching #endif (tools/build_variant.py <tag> -DMVD_PROBE)
-// ---------------------------------------------------------------- 64 queries per wave (engine form only; experiment)
-// Measured (profiles/r03_probe_attention_q64.log): 4096 x 4096 x 5 heads x 32 pairs on random data 790 -> 737 us, but IN SITU
-// (the forward's own activations, where the 32-query kernel already runs 1.05-1.08 PFLOP/s) 1051 vs 1055 TFLOP/s -- nothing --
-// and at 9216 keys (96 x 96 latents) the step is 1 % slower; shorter sequences lose outright.  Probe builds only.
-// The engine form (PRE + DMA + VSUM) with TWO 32-query sub-tiles per wave: every K fragment (ds_read_b128) and every V^T
-// fragment (two ds_read_b64_tr_b16) feeds two MFMAs instead of one -- half the LDS reads and half the per-tile fixed costs
-// (barrier, DMA issue, loop) per FLOP -- and the two sub-tiles' softmax / MFMA streams are independent, so one's
-// exponentials can issue under the other's MFMAs inside ONE wave.  The price is registers: 2 x (32 score + 32 output + 16
-// running-max tile + 16 Q) + ... ~ 250, i.e. TWO waves per SIMD instead of four.  NW waves x 64 queries per workgroup.
-template <int NW>
-__global__ __launch_bounds__(64 * NW, 2) void attn_q64_kernel(const MvdAttnArgs a) {
-  constexpr int NT = 64 * NW, QS = 2, NSUB = 2;
-  constexpr int QB = 32 * NW * QS;
-  constexpr int KV_TILE = 32 * NSUB;
-  constexpr int TILE_BYTES = KV_TILE * 128;
-  constexpr int LD_IT = (KV_TILE * 8) / NT;
-  static_assert((KV_TILE * 8) % NT == 0 && (NT / 8) % 16 == 0, "tile must divide over threads; DMA rows of a lane share the swizzle pattern");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];         // 4 * TILE_BYTES: K0 K1 V0 V1
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lq = lane & 31, lh = lane >> 5;
-  int qb_, head, bz;
-  attn_block(a, qb_, head, bz);
-  const int pi = bz / a.batch;
-  bz -= pi * a.batch;
-  const MvdAttnProblem& P = a.p[pi];
-  const int nq = P.nq, nk = P.nk;
-  const int qblk0 = qb_ * QB;
-  if (qblk0 >= nq) return;
-
-  const bf16_t* qp = P.q + (size_t)bz * P.bsq + head * 64;
-  const bf16_t* kp = P.k + (size_t)bz * P.bsk + head * 64;
-  const bf16_t* vp = P.v + (size_t)bz * P.bsv + head * 64;
-  bf16_t* op = P.o + (size_t)bz * P.bso + head * 64;
-
-  // Q fragments live in LDS (behind the K/V stages: 8 KB per wave, K's swizzle) and are re-read per tile -- 32 registers this
-  // kernel does not have; each wave writes and reads only its own rows
-  unsigned char* sq = smem + 4 * TILE_BYTES + wave * (QS * 32 * 128);
-#pragma unroll
-  for (int u = 0; u < QS; ++u) {
-    const int qrow = qblk0 + (wave * QS + u) * 32 + lq;
-    const int qrow_c = qrow < nq ? qrow : nq - 1;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-      *reinterpret_cast<bf16x8*>(sq + u * 4096 + k_off(lq, ks * 2 + lh)) = *reinterpret_cast<const bf16x8*>(qp + (size_t)qrow_c * P.ldq + ks * 16 + lh * 8);
-  }
-
-  const int ld_kc = tid & 7, ld_row = tid >> 3;
-  const int ldk = P.ldk, ldv = P.ldv;
-  typedef __attribute__((address_space(3))) void lds_void_t;
-  __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(kp), 0, (nk - 1) * ldk * 2 + 128, 0x00020000);
-  __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vp), 0, (nk - 1) * ldv * 2 + 128, 0x00020000);
-  const unsigned dma_ko = (unsigned)ld_row * (unsigned)ldk * 2u + ((ld_kc ^ ((ld_row >> 1) & 7)) << 4);
-  const unsigned dma_vo = (unsigned)ld_row * (unsigned)ldv * 2u + ((ld_kc ^ (((ld_row >> 1) & 1) << 2)) << 4);
-  auto dma_tile = [&](int kb, int st) {
-    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-    unsigned char* dk = smem + st * TILE_BYTES + wave_s * 1024;
-    unsigned char* dv = smem + (2 + st) * TILE_BYTES + wave_s * 1024;
-#pragma unroll
-    for (int i = 0; i < LD_IT; ++i) {
-      const int row0 = kb * KV_TILE + i * (NT / 8);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lds_void_t*)(dk + i * (NT / 8) * 128), 16, (int)dma_ko, row0 * ldk * 2, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lds_void_t*)(dv + i * (NT / 8) * 128), 16, (int)dma_vo, row0 * ldv * 2, 0, 0);
-    }
-  };
-
-  f32x16 o0[QS], o1[QS], negm[QS];
-  f32x4 lacc[QS];
-  float m_run[QS];
-#pragma unroll
-  for (int u = 0; u < QS; ++u) { o0[u] = f32x16{}; o1[u] = f32x16{}; negm[u] = f32x16{}; lacc[u] = f32x4{0.f, 0.f, 0.f, 0.f}; m_run[u] = 0.f; }
-  bf16x8 sel;                                  // (the selector of attn_kernel's VSUM form)
-  {
-    const int sm = lane & 15, sg = (lane >> 4) & 1;
-    const __bf16 one = (sm == sg && sm < 2) ? (__bf16)1.0f : (__bf16)0.0f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) sel[j] = one;
-  }
-
-  const int nkb = (nk + KV_TILE - 1) / KV_TILE;
-  dma_tile(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  const int tr_i = lane & 15;
-  const int tr_q = tr_i >> 2, tr_p = tr_i & 3;
-  const int tr_dcol = ((lane >> 4) & 1) * 16 + tr_p * 4;
-  const int tr_base0 = v_off(4 * lh + tr_q, tr_dcol >> 3) + (tr_dcol & 7) * 2;
-  const int tr_base1 = tr_base0 ^ 64;
-  int k_base[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) k_base[ks] = k_off(lq, ks * 2 + lh);
-
-  for (int kb = 0; kb < nkb; ++kb) {
-    const int cur = kb & 1;
-    const bool more = kb + 1 < nkb;
-    if (more) dma_tile(kb + 1, cur ^ 1);
-    const unsigned char* sk = smem + cur * TILE_BYTES;
-    const unsigned char* sv = smem + (2 + cur) * TILE_BYTES;
-
-    // ---- S^T = K.Q^T: one K fragment, two query sub-tiles
-    f32x16 s[QS][NSUB];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-      for (int t = 0; t < NSUB; ++t) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + k_base[ks] + t * 32 * 128);
-#pragma unroll
-        for (int u = 0; u < QS; ++u) {
-          const bf16x8 qfr = *reinterpret_cast<const bf16x8*>(sq + u * 4096 + k_base[ks]);
-          if (ks == 0) s[u][t] = mfma_from(kf, qfr, negm[u]);
-          else s[u][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qfr, s[u][t], 0, 0, 0);
-        }
-      }
-    }
-    if (kb * KV_TILE + KV_TILE > nk) {
-#pragma unroll
-      for (int u = 0; u < QS; ++u)
-#pragma unroll
-        for (int t = 0; t < NSUB; ++t)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int key = kb * KV_TILE + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (key >= nk) s[u][t][r] = NEG_BIG;
-          }
-    }
-    // ---- online softmax, deferred rescale; one vote for both sub-tiles
-    float mx[QS];
-#pragma unroll
-    for (int u = 0; u < QS; ++u) {
-      mx[u] = s[u][0][0];
-#pragma unroll
-      for (int t = 0; t < NSUB; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx[u] = fmaxf(mx[u], s[u][t][r]);
-    }
-    if (kb == 0 || !__all(fmaxf(mx[0], mx[1]) <= RESCALE_LOG2)) {
-#pragma unroll
-      for (int u = 0; u < QS; ++u) {
-        const float mxu = pair_max(mx[u]);
-        const float delta = kb == 0 ? mxu : fmaxf(mxu, 0.f);
-        if (kb != 0) {
-          const float alpha = __builtin_amdgcn_exp2f(-delta);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) { o0[u][r] *= alpha; o1[u][r] *= alpha; }
-          lacc[u][0] *= alpha;
-          lacc[u][1] *= __shfl(alpha, (lane + 16) & 63, 64);
-        }
-        m_run[u] += delta;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) negm[u][r] = -m_run[u];
-#pragma unroll
-        for (int t = 0; t < NSUB; ++t)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) s[u][t][r] -= delta;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < QS; ++u)
-#pragma unroll
-      for (int t = 0; t < NSUB; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[u][t][r] = __builtin_amdgcn_exp2f(s[u][t][r]);
-
-    // ---- O^T += V^T . P^T: one V^T fragment, two query sub-tiles
-#pragma unroll
-    for (int st = 0; st < 2 * NSUB; ++st) {
-      bf16x8 pb[QS];
-#pragma unroll
-      for (int u = 0; u < QS; ++u)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pb[u][j] = (__bf16)s[u][st >> 1][8 * (st & 1) + j];
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        const int offA = (dt == 0 ? tr_base0 : tr_base1) + st * 16 * 128;
-        const int offB = offA + 8 * 128;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sv + offA));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sv + offB));
-        typedef __attribute__((ext_vector_type(8))) short s16x8;
-        const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        const bf16x8 vf = __builtin_bit_cast(bf16x8, both);
-#pragma unroll
-        for (int u = 0; u < QS; ++u) {
-          if (dt == 0) o0[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[u], o0[u], 0, 0, 0);
-          else         o1[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[u], o1[u], 0, 0, 0);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < QS; ++u) lacc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sel, pb[u], lacc[u], 0, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-
-#pragma unroll
-  for (int u = 0; u < QS; ++u) {
-    const float d0 = __shfl(lacc[u][0], lq & 15, 64), d1 = __shfl(lacc[u][1], lq & 15, 64);
-    const float inv = 1.0f / (lq < 16 ? d0 : d1);
-    const int qrow = qblk0 + (wave * QS + u) * 32 + lq;
-    if (qrow < nq) {
-      bf16_t* orow = op + (size_t)qrow * P.ldo;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        u32x2 w0 = {pack2bf(o0[u][4 * g] * inv, o0[u][4 * g + 1] * inv), pack2bf(o0[u][4 * g + 2] * inv, o0[u][4 * g + 3] * inv)};
-        u32x2 w1 = {pack2bf(o1[u][4 * g] * inv, o1[u][4 * g + 1] * inv), pack2bf(o1[u][4 * g + 2] * inv, o1[u][4 * g + 3] * inv)};
-        *reinterpret_cast<u32x2*>(orow + 8 * g + 4 * lh) = w0;
-        *reinterpret_cast<u32x2*>(orow + 32 + 8 * g + 4 * lh) = w1;
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// Software-pipelined variant (prescaled Q, 64-key tiles, 4 waves x 32 queries, two waves per SIMD / 256 registers):
-// the S^T = K.Q^T MFMAs of tile t+1 are issued UNDER the softmax of tile t (their accumulator is a second register
-// set), so the matrix pipe has work while the exp / convert stream of tile t runs, and the exp stream has MFMA shadows
-// to hide in.  K therefore runs one tile ahead of V through LDS: iteration t reads V(t) and K(t+1).
-template <int NW>
-__global__ __launch_bounds__(64 * NW, 2) void attn_pipe_kernel(const MvdAttnArgs a) {
-  constexpr int NT = 64 * NW;
-  constexpr int QB = 32 * NW;
-  constexpr int KV_TILE = 64;
-  constexpr int TILE_BYTES = KV_TILE * 128;
-  constexpr int LD_IT = (KV_TILE * 8) / NT;
-  static_assert((NT / 8) % 16 == 0, "loader rows must share the swizzle pattern");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];  // K0 K1 V0 V1
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lq = lane & 31, lh = lane >> 5;
-  int qb_, head, bz;
-  attn_block(a, qb_, head, bz);
-  const int pi = bz / a.batch;
-  bz -= pi * a.batch;
-  const MvdAttnProblem& P = a.p[pi];
-  const int nq = P.nq, nk = P.nk;
-  const int qblk0 = qb_ * QB;
-  if (qblk0 >= nq) return;
-
-  const bf16_t* qp = P.q + (size_t)bz * P.bsq + head * 64;
-  const bf16_t* kp = P.k + (size_t)bz * P.bsk + head * 64;
-  const bf16_t* vp = P.v + (size_t)bz * P.bsv + head * 64;
-  bf16_t* op = P.o + (size_t)bz * P.bso + head * 64;
-
-  const int qrow = qblk0 + wave * 32 + lq;
-  const int qrow_c = qrow < nq ? qrow : nq - 1;
-  bf16x8 qf[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks)
-    qf[ks] = *reinterpret_cast<const bf16x8*>(qp + (size_t)qrow_c * P.ldq + ks * 16 + lh * 8);
-
-  const int ld_kc = tid & 7, ld_row = tid >> 3;
-  const int ld_koff = k_off(ld_row, ld_kc), ld_voff = v_off(ld_row, ld_kc);
-  const int ldk = P.ldk, ldv = P.ldv;
-  const unsigned ld_ko = ((unsigned)ld_row * (unsigned)ldk + ld_kc * 8) * 2u;
-  const unsigned ld_vo = ((unsigned)ld_row * (unsigned)ldv + ld_kc * 8) * 2u;
-  const char* kp_b = reinterpret_cast<const char*>(kp);
-  const char* vp_b = reinterpret_cast<const char*>(vp);
-  u32x4 rk[LD_IT], rv[LD_IT];
-  // one operand (K or V) of key tile kb: uniform base + loop-invariant per-lane offset; ragged last tile clamps rows
-  auto load_one = [&](const char* base, int ld, unsigned lane_off, int kb, u32x4 (&r)[LD_IT]) __attribute__((always_inline)) {
-    const int k0 = kb * KV_TILE;
-    const bool full = k0 + KV_TILE <= nk;
-#pragma unroll
-    for (int i = 0; i < LD_IT; ++i) {
-      const char* b = base;
-      unsigned o;
-      if (full) {
-        b += (size_t)(k0 + i * (NT / 8)) * ld * 2;
-        o = lane_off;
-      } else {
-        int key = k0 + ld_row + i * (NT / 8);
-        key = key < nk ? key : nk - 1;
-        asm volatile("" : "+v"(key));
-        o = ((unsigned)key * (unsigned)ld + ld_kc * 8) * 2u;
-      }
-      r[i] = *reinterpret_cast<const u32x4*>(b + o);
-    }
-  };
-  auto store_k = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < LD_IT; ++i) *reinterpret_cast<u32x4*>(smem + buf * TILE_BYTES + ld_koff + i * (NT / 8) * 128) = rk[i];
-  };
-  auto store_v = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < LD_IT; ++i) *reinterpret_cast<u32x4*>(smem + (2 + buf) * TILE_BYTES + ld_voff + i * (NT / 8) * 128) = rv[i];
-  };
-
-  f32x16 o0 = {}, o1 = {}, ol = {};
-  bf16x8 ones_frag;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) ones_frag[j] = (lq == 0) ? (__bf16)1.0f : (__bf16)0.0f;
-  float m_run = 0.f;
-  f32x16 negm = {};
-  f32x16 sA[2], sB[2];           // score accumulators of the tile being reduced / of the tile being multiplied
-
-  const int tr_i = lane & 15;
-  const int tr_q = tr_i >> 2, tr_p = tr_i & 3;
-  const int tr_dcol = ((lane >> 4) & 1) * 16 + tr_p * 4;
-  const int tr_base0 = v_off(4 * lh + tr_q, tr_dcol >> 3) + (tr_dcol & 7) * 2;
-  const int tr_base1 = tr_base0 ^ 64;
-  int k_base[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) k_base[ks] = k_off(lq, ks * 2 + lh);
-
-  auto qk = [&](int kbuf, f32x16 (&s)[2]) __attribute__((always_inline)) {
-    const unsigned char* sk = smem + kbuf * TILE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + k_base[ks] + t * 32 * 128);
-        if (ks == 0) s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0], negm, 0, 0, 0);
-        else         s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t], 0, 0, 0);
-      }
-    }
-  };
-
-  const int nkb = (nk + KV_TILE - 1) / KV_TILE;
-  // ---- prologue: K(0), K(1), V(0) -> LDS ; S(0)
-  load_one(kp_b, ldk, ld_ko, 0, rk); store_k(0);
-  if (nkb > 1) { load_one(kp_b, ldk, ld_ko, 1, rk); store_k(1); }
-  load_one(vp_b, ldv, ld_vo, 0, rv); store_v(0);
-  __syncthreads();
-  qk(0, sA);
-
-  // iteration kb: s = scores of tile kb (relative to the running max they were started from), sn <- scores of tile kb+1
-  auto body = [&](int kb, int par, f32x16 (&s)[2], f32x16 (&sn)[2]) __attribute__((always_inline)) {
-    const bool have1 = kb + 1 < nkb, have2 = kb + 2 < nkb;
-    if (have2) load_one(kp_b, ldk, ld_ko, kb + 2, rk);
-    if (have1) load_one(vp_b, ldv, ld_vo, kb + 1, rv);
-    if (kb * KV_TILE + KV_TILE > nk) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kb * KV_TILE + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (key >= nk) s[t][r] = NEG_BIG;
-        }
-    }
-    float mx = s[0][0];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
-    mx = pair_max(mx);
-    if (kb == 0 || !__all(mx <= RESCALE_LOG2)) {
-      const float delta = kb == 0 ? mx : fmaxf(mx, 0.f);
-      if (kb != 0) {
-        const float alpha = __builtin_amdgcn_exp2f(-delta);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-        ol[0] *= alpha;
-      }
-      m_run += delta;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) negm[r] = -m_run;
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[t][r] -= delta;
-    }
-    // scores of the NEXT tile, started from the (possibly just raised) running max, interleaved at k-step granularity
-    // with the exponentials of THIS tile: two MFMAs (64 matrix-pipe cycles), then the eight v_exp_f32 of one 16-key
-    // group (64 issue cycles) in their shadow; the K fragments of the next k-step are already in flight
-    if (have1) {
-      const unsigned char* sk = smem + (par ^ 1) * TILE_BYTES;
-      bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(sk + k_base[0]);
-      bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(sk + k_base[0] + 32 * 128);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        bf16x8 nf0 = kf0, nf1 = kf1;
-        if (ks < 3) {
-          nf0 = *reinterpret_cast<const bf16x8*>(sk + k_base[ks + 1]);
-          nf1 = *reinterpret_cast<const bf16x8*>(sk + k_base[ks + 1] + 32 * 128);
-        }
-        if (ks == 0) {
-          sn[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0, qf[0], negm, 0, 0, 0);
-          sn[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1, qf[0], negm, 0, 0, 0);
-        } else {
-          sn[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0, qf[ks], sn[0], 0, 0, 0);
-          sn[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1, qf[ks], sn[1], 0, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s[ks >> 1][8 * (ks & 1) + j] = __builtin_amdgcn_exp2f(s[ks >> 1][8 * (ks & 1) + j]);
-        __builtin_amdgcn_sched_barrier(0);
-        kf0 = nf0; kf1 = nf1;
-      }
-    } else {
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[t][r] = __builtin_amdgcn_exp2f(s[t][r]);
-    }
-    const unsigned char* sv = smem + (2 + par) * TILE_BYTES;
-#pragma unroll
-    for (int st = 0; st < 4; ++st) {
-      bf16x8 pb;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) pb[j] = (__bf16)s[st >> 1][8 * (st & 1) + j];
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        const int offA = (dt == 0 ? tr_base0 : tr_base1) + st * 16 * 128;
-        const int offB = offA + 8 * 128;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sv + offA));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sv + offB));
-        typedef __attribute__((ext_vector_type(8))) short s16x8;
-        const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        const bf16x8 vf = __builtin_bit_cast(bf16x8, both);
-        if (dt == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, o0, 0, 0, 0);
-        else         o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, o1, 0, 0, 0);
-      }
-      ol = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones_frag, pb, ol, 0, 0, 0);
-    }
-    if (have2) store_k(par);          // K(kb+2) over K(kb): its S^T was formed one iteration ago
-    if (have1) store_v(par ^ 1);      // V(kb+1) over V(kb-1)
-    __syncthreads();
-  };
-  for (int kb = 0;;) {
-    body(kb, 0, sA, sB);
-    if (++kb >= nkb) break;
-    body(kb, 1, sB, sA);
-    if (++kb >= nkb) break;
-  }
-
-  const float inv = 1.0f / pair_sum(ol[0]);
-  if (qrow < nq) {
-    bf16_t* orow = op + (size_t)qrow * P.ldo;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      u32x2 w0 = {pack2bf(o0[4 * g] * inv, o0[4 * g + 1] * inv), pack2bf(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv)};
-      u32x2 w1 = {pack2bf(o1[4 * g] * inv, o1[4 * g + 1] * inv), pack2bf(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv)};
-      *reinterpret_cast<u32x2*>(orow + 8 * g + 4 * lh) = w0;
-      *reinterpret_cast<u32x2*>(orow + 32 + 8 * g + 4 * lh) = w1;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// "Ping-pong" attention (prescaled Q, 64-key tiles): 8 waves x 32 queries per workgroup, one workgroup per CU, the two
-// waves of every SIMD (waves w and w + 4) ONE PHASE APART, as in gemm_pp.hip.  A wave's key tile t is two phases, each
-// closed by a raw s_barrier:
-//     A_t (matrix):  O^T += V(t-1)^T . P(t-1)^T  (12 MFMAs incl. the row-sum tile)  and  S(t)^T = K(t) . Q^T  (8 MFMAs)
-//     B_t (vector):  online softmax of S(t) -> bf16 P(t) in registers  (max, deferred rescale, 32 v_exp, 16 v_cvt_pk)
-// so while one wave of a SIMD feeds the matrix pipe its partner runs the exponentials -- the overlap the free-running
-// 3-waves-per-SIMD kernel above only gets statistically (its SQ counters: matrix pipe 54 % busy, vector issue 67 %).
-// The matrix phase runs OUT OF REGISTERS: the K(t+1) and V(t) fragments it needs are read from LDS during the vector
-// phase B_t (whose LDS port is otherwise idle), so A is 20 back-to-back MFMAs.
-// K/V tiles arrive by buffer-addressed LDS-DMA (wave w loads the w-th 8-key piece of each tile: no VGPR round trip, no
-// ds_write; keys >= nk lie beyond num_records and read as zeros) into THREE-stage rings: at the END of B_t a wave issues
-// K(t+3) and V(t+2) and waits for them at the end of its B_{t+1} -- two whole phases of cover.
-// (g = barrier generation: group 0 leaves A_t at 2t, B_t at 2t+1; group 1 one later.  WAR: stage of K(t+3) = stage of
-//  K(t), last read in B_{t-1}, which both groups have left by g = 2t, before either issues (end of B_t).  V(t+2) likewise
-//  replaces V(t-1).  RAW: K(t+3) / V(t+2) are first read by group 0 in B_{t+2}, behind g = 2t+4; group 0's wait sits
-//  before g = 2t+3, group 1's before 2t+4.)
-__global__ __launch_bounds__(512, 2) void attn_pp_kernel(const MvdAttnArgs a) {
-  constexpr int QB = 256, KV_TILE = 64, TILE_BYTES = KV_TILE * 128, NSTG = 3;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * NSTG * TILE_BYTES];   // K ring | V ring
-  typedef __attribute__((address_space(3))) void lds_void;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2;
-  const int lq = lane & 31, lh = lane >> 5;
-  const int head = blockIdx.y;
-  int bz = blockIdx.z;
-  const int pi = bz / a.batch;
-  bz -= pi * a.batch;
-  const MvdAttnProblem& P = a.p[pi];
-  const int nq = P.nq, nk = P.nk;
-  const int qblk0 = blockIdx.x * QB;
-  if (qblk0 >= nq) return;  // whole workgroup exits together (uniform)
-
-  const bf16_t* qp = P.q + (size_t)bz * P.bsq + head * 64;
-  bf16_t* op = P.o + (size_t)bz * P.bso + head * 64;
-  const int qrow = qblk0 + wave * 32 + lq;
-  const int qrow_c = qrow < nq ? qrow : nq - 1;
-  bf16x8 qf[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks)
-    qf[ks] = *reinterpret_cast<const bf16x8*>(qp + (size_t)qrow_c * P.ldq + ks * 16 + lh * 8);
-
-  // ---- K/V loader: buffer descriptors over this batch element's rows; per-lane offset = key-in-piece row + head + chunk
-  // (the XOR swizzles of k_off / v_off live on the SOURCE side: the DMA writes lane-linear)
-  const int ldk2 = P.ldk * 2, ldv2 = P.ldv * 2;
-  __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(P.k + (size_t)bz * P.bsk), 0, (int)((size_t)nk * ldk2), 0x00020000);
-  __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(P.v + (size_t)bz * P.bsv), 0, (int)((size_t)nk * ldv2), 0x00020000);
-  const int ld_key = wave * 8 + (lane >> 3);                          // key row inside the tile this lane fetches
-  const unsigned vo_k = (unsigned)ld_key * (unsigned)ldk2 + head * 128 + (((lane & 7) ^ ((ld_key >> 1) & 7)) << 4);
-  const unsigned vo_v = (unsigned)ld_key * (unsigned)ldv2 + head * 128 + (((lane & 7) ^ (((ld_key >> 1) & 1) << 2)) << 4);
-  const int nkb = (nk + KV_TILE - 1) / KV_TILE;
-  auto load_k = [&](int t) {   // K tile t -> K ring stage t % 3
-    if (t < nkb) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lds_void*)(smem + (t % NSTG) * TILE_BYTES + wave * 1024), 16, (int)vo_k,
-                                                          t * KV_TILE * ldk2, 0, 0);
-  };
-  auto load_v = [&](int t) {
-    if (t < nkb) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lds_void*)(smem + (NSTG + t % NSTG) * TILE_BYTES + wave * 1024), 16, (int)vo_v,
-                                                          t * KV_TILE * ldv2, 0, 0);
-  };
-
-  f32x16 o0 = {}, o1 = {}, ol = {};
-  bf16x8 ones_frag;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) ones_frag[j] = (lq == 0) ? (__bf16)1.0f : (__bf16)0.0f;
-  float m_run = 0.f;
-  f32x16 negm = {};
-  f32x16 s[2];
-  bf16x8 pb[4];                   // bf16 P of the tile whose P.V is pending: k-step st = keys 16 st .. 16 st + 15
-
-  const int tr_i = lane & 15;
-  const int tr_q = tr_i >> 2, tr_p = tr_i & 3;
-  const int tr_dcol = ((lane >> 4) & 1) * 16 + tr_p * 4;
-  const int tr_base0 = v_off(4 * lh + tr_q, tr_dcol >> 3) + (tr_dcol & 7) * 2;
-  const int tr_base1 = tr_base0 ^ 64;
-  int k_base[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) k_base[ks] = k_off(lq, ks * 2 + lh);
-
-  auto phase_end = [&]() {
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  // Fragment registers of ONE matrix phase, filled in the vector phase before it: the matrix phase is then 20 MFMAs
-  // out of registers (640 matrix-pipe cycles, no LDS wait inside).
-  bf16x8 kfr[4][2];               // K(t+1) rows: [k-step][32-key sub tile]
-  bf16x8 vfr[4][2];               // V(t)^T:      [16-key k-step][32-dim tile]
-  auto read_k = [&](int t) {
-    const unsigned char* sk = smem + (t % NSTG) * TILE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) kfr[ks][u] = *reinterpret_cast<const bf16x8*>(sk + k_base[ks] + u * 32 * 128);
-  };
-  auto read_v = [&](int t) {
-    const unsigned char* sv = smem + (NSTG + t % NSTG) * TILE_BYTES;
-#pragma unroll
-    for (int st = 0; st < 4; ++st)
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        const int offA = (dt == 0 ? tr_base0 : tr_base1) + st * 16 * 128;
-        const int offB = offA + 8 * 128;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sv + offA));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sv + offB));
-        typedef __attribute__((ext_vector_type(8))) short s16x8;
-        const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        vfr[st][dt] = __builtin_bit_cast(bf16x8, both);
-      }
-  };
-  auto pv = [&]() {               // O^T += V^T . P^T, row sums on the "ones" tile
-#pragma unroll
-    for (int st = 0; st < 4; ++st) {
-      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[st][0], pb[st], o0, 0, 0, 0);
-      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[st][1], pb[st], o1, 0, 0, 0);
-      ol = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones_frag, pb[st], ol, 0, 0, 0);
-    }
-  };
-  auto qk = [&]() {               // S^T = K . Q^T, started at -running max (exp2 domain)
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        if (ks == 0) s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[0][u], qf[0], negm, 0, 0, 0);
-        else         s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[ks][u], qf[ks], s[u], 0, 0, 0);
-      }
-  };
-  auto softmax = [&](int kb) {    // exactly the arithmetic of attn_kernel<.., PRE = true>
-    if (kb * KV_TILE + KV_TILE > nk) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kb * KV_TILE + u * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (key >= nk) s[u][r] = NEG_BIG;
-        }
-    }
-    float mx = s[0][0];
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[u][r]);
-    mx = pair_max(mx);
-    if (kb == 0 || !__all(mx <= RESCALE_LOG2)) {
-      const float delta = kb == 0 ? mx : fmaxf(mx, 0.f);
-      if (kb != 0) {
-        const float alpha = __builtin_amdgcn_exp2f(-delta);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-        ol[0] *= alpha;
-      }
-      m_run += delta;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) negm[r] = -m_run;
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[u][r] -= delta;
-    }
-#pragma unroll
-    for (int st = 0; st < 4; ++st)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) pb[st][j] = (__bf16)__builtin_amdgcn_exp2f(s[st >> 1][8 * (st & 1) + j]);
-  };
-
-  // ---- prologue (all waves together): K(0..2), V(0..1) land; K(0)'s fragments go to registers
-  load_k(0); load_v(0); load_k(1); load_v(1); load_k(2);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  phase_end();
-  read_k(0);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  if (grp == 1) phase_end();             // the stagger
-  for (int t = 0; t < nkb; ++t) {
-    // ---- A_t: pure MFMA
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-#ifdef MVD_PROBE
-    if (!(a.dbg & 16))
+#ifdef MVD_PROBE   // measurement-only kernels: probe builds only (tools/build_variant.py <tag> -DMVD_PROBE)
+#include "probe/attention_probe.inc"
 #endif
-    {
-    if (t > 0) pv();                     // P(t-1) . V(t-1)
-    qk();                                // K(t) . Q^T
-    }
-    __builtin_amdgcn_s_setprio(0);
-    phase_end();
-    // ---- B_t: softmax(t); fragments of the next matrix phase; then the loads two / three tiles ahead
-#ifdef MVD_PROBE
-    if (!(a.dbg & 4))
-#endif
-    {
-    read_v(t);                           // (first: the LDS latency hides under the exponentials)
-    if (t + 1 < nkb) read_k(t + 1);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#ifdef MVD_PROBE
-    if (!(a.dbg & 8))
-#endif
-    softmax(t);
-#ifdef MVD_PROBE
-    if (a.dbg & 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else
-#endif
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's loads issued at the end of B_{t-1}; this phase's reads
-#ifdef MVD_PROBE
-    if (!(a.dbg & 2))
-#endif
-    { load_k(t + 3); load_v(t + 2); }
-    phase_end();
-  }
-  // ---- drain: the last tile's P.V
-  __builtin_amdgcn_s_setprio(1);
-  pv();
-  __builtin_amdgcn_s_setprio(0);
-  phase_end();
-  if (grp == 0) phase_end();             // balance the stagger
-
-  const float inv = 1.0f / pair_sum(ol[0]);
-  if (qrow < nq) {
-    bf16_t* orow = op + (size_t)qrow * P.ldo;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      u32x2 w0 = {pack2bf(o0[4 * g] * inv, o0[4 * g + 1] * inv), pack2bf(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv)};
-      u32x2 w1 = {pack2bf(o1[4 * g] * inv, o1[4 * g + 1] * inv), pack2bf(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv)};
-      *reinterpret_cast<u32x2*>(orow + 8 * g + 4 * lh) = w0;
-      *reinterpret_cast<u32x2*>(orow + 32 + 8 * g + 4 * lh) = w1;
-    }
-  }
-}
-
-#endif  // MVD_PROBE
 
 thread_local int g_last_attn[2] = {0, 0};
 static int g_attn_pipe_override = 0;
 static int g_attn_q64_override = 0;     // measurement hook (probe builds): 64 queries per wave, 4 (2) or 2 (1) waves per workgroup
 
 #ifdef MVD_PROBE
-template <int NW>
-int launch_q64(const MvdAttnArgs& a, int maxq, hipStream_t s) {
-  const int qb = 64 * NW;
-  dim3 grid(((maxq + qb - 1) / qb) * a.heads * a.batch * a.nprob);
-  g_last_attn[0] = NW; g_last_attn[1] = (int)grid.x;
-  static bool init = false;
-  if (!init) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_q64_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32 * 2 * 128 + NW * 8192);
-    if (e != hipSuccess) { mvd_set_error("attention (64 queries per wave): hipFuncSetAttribute: %s", hipGetErrorString(e)); return -2; }
-    init = true;
-  }
-  hipLaunchKernelGGL((attn_q64_kernel<NW>), grid, dim3(64 * NW), 4 * 32 * 2 * 128 + NW * 8192, s, a);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) { mvd_set_error("attention (64 queries per wave) launch: %s", hipGetErrorString(e)); return -3; }
-  return 0;
-}
+#include "probe/attention_probe_launch.inc"
 #endif
 
 template <int NW, int NSUB>

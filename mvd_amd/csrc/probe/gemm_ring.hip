@@ -16,7 +16,7 @@
 // (A four-wave / 512-register variant with 128x160 wave tiles was tried first: hipcc cannot allocate it -- the
 //  accumulators bounce between AGPRs, VGPRs and scratch.)
 #include <stdlib.h>
-#include "kernels.h"
+#include "../kernels.h"
 
 namespace {
 

@@ -13,7 +13,7 @@ tag, defs = sys.argv[1], sys.argv[2:]
 objdir = os.path.join(B.CSRC, "build_" + tag)
 os.makedirs(objdir, exist_ok=True)
 def cc(src):
-    o = os.path.join(objdir, src.replace(".hip", ".o"))
+    o = os.path.join(objdir, os.path.basename(src).replace(".hip", ".o"))
     subprocess.run([B.HIPCC, *B.FLAGS, *defs, "-c", os.path.join(B.CSRC, src), "-o", o], check=True)
     return o
 with ThreadPoolExecutor(4) as ex:
