@@ -632,12 +632,14 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
 template <int BM, int WM, int WN, int AMODE, bool SPLITK, bool LNF = false>
 int launch_pp(const MvdGemmArgs& a, hipStream_t s) {
   constexpr int LDS_BYTES = 2 * (BM * 128 + B_BYTES) + (LNF ? XCH_BYTES : 0);
-  static bool init = false;
-  if (!init) {
+  static bool init[16] = {};                            // per device
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!init[dev & 15]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<BM, WM, WN, AMODE, SPLITK, LNF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) { mvd_set_error("gemm_pp: hipFuncSetAttribute: %s", hipGetErrorString(e)); return -2; }
-    init = true;
+    init[dev & 15] = true;
   }
   const int ntm = (a.M + BM - 1) / BM, ntn = a.N / BN;
   int grid = 256;                                         // one 144 KB (112 KB at BM = 128) workgroup per CU

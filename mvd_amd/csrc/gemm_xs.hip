@@ -367,11 +367,13 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const MvdXsArgs a) {
 template <int KS, bool GEGLU, bool RES, bool LN>
 int launch_xs(const MvdXsArgs& a, hipStream_t s) {
   constexpr int LDS_BYTES = 3 * (KS + 1) * 1024 + 4 * 4096;     // ring + the per-wave store staging
-  static bool init = false;
-  if (!init) {
+  static bool init[16] = {};                            // per device
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!init[dev & 15]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_xs_kernel<KS, GEGLU, RES, LN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) { mvd_set_error("gemm_xs: hipFuncSetAttribute: %s", hipGetErrorString(e)); return -2; }
-    init = true;
+    init[dev & 15] = true;
     if (MVD_ENV_INT("MVD_XS_TRACE", 0)) {     // (probe builds only)
       int occ = -1;
       (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(&gemm_xs_kernel<KS, GEGLU, RES, LN>), 256, LDS_BYTES);

@@ -45,9 +45,10 @@ struct MvdGemmArgs {
   float* part;            // [splitk][M][N] fp32 partials (then mvd_launch_splitk_reduce applies the epilogue)
   int w_blocked;          // gemm_sm.hip only: W is stored as [N/32][K/64] blocks of 32 rows x 64 k in LDS-image order (packing.block_weight)
   int splitk_nowait;      // gemm_sm.hip split-K: 1 = the slice that arrives last combines the whole tile and nobody waits (launches that
-                          // may share the chip with another stream's kernels); 0 = the slices rendezvous and each combines a share
-  unsigned int* tile_cnt; // gemm_sm.hip split-K only: one ZEROED arrival counter per output tile (the slice that takes the last
-                          // ticket combines the partials in the kernel: no reduce launch)
+                          // share the chip with another stream's kernels by design); 0 = the slices rendezvous for a BOUNDED time and each
+                          // combines a share; the last arriver combines whatever was not claimed (safe under any residency)
+  unsigned int* tile_cnt; // gemm_sm.hip split-K only: one ZEROED word per output tile (arrival count in bits 0-7, one claim bit per
+                          // share above: the slices combine the partials in the kernel, no reduce launch; splitk <= 24)
   int dbg;                // probe builds only (-DMVD_PROBE, env MVD_GEMM_DEBUG): bit0 skip the output stores, bit1 skip the MFMAs
   // LayerNorm fold (ping-pong kernels only, see mvd_gemm_ln_fold_ok): A holds the UN-normalised rows x, W holds
   // W.diag(gamma), ln_c1[n] = sum_k W[n][k] (of the bf16 values), bias[n] = sum_k beta[k].W0[n][k] + b[n]; the kernel

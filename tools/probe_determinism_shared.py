@@ -48,3 +48,21 @@ qkv = rnd(B, 4096, 960)
 check("attention 32x5x4096x4096 (engine form)", lambda: ops.attention(qkv[:, :, :320], qkv[:, :, 320:640], qkv[:, :, 640:], 5, scale=0.0))
 sc, sh = torch.randn(B, 320, device=dev), torch.randn(B, 320, device=dev)
 check("film 32x4096x320", lambda: ops.film(xf, sc, sh) if hasattr(ops, "film") else xf)
+
+# ---- round 4: the in-kernel rendezvous forms with a second tenant on the GPU -- the small-M kernels' split-K
+# combine (bounded wait + claims, gemm_sm.hip), the split-KV attention merge (ticket, last arriver), and the X-stationary
+# kernels.  A batch-1 forward's shapes: the deep-level convolutions / projections split 4-16 ways.
+from mvd_amd.packing import pack_xs
+x8 = rnd(1, 8, 8, 1280)
+w8 = rnd(1280, 9 * 1280); b8 = torch.randn(1280, device=dev)
+for S in (4, 12, 16):
+    check(f"gemm_sm conv3x3 1x8x8 1280->1280 split-K {S} (in-kernel rendezvous)", lambda S=S: ops.conv3x3(x8, w8, b8, force_cfg=100, splitk=S))
+a1 = rnd(256, 5120); w1 = rnd(1280, 5120)
+check("gemm_sm linear 256x1280x5120 split-K 8 + residual", lambda: ops.linear(a1, w1, b8, res=rnd(256, 1280) * 0 + 1, force_cfg=100, splitk=8))
+q1 = rnd(1, 4096, 960)
+for ns in (2, 3):
+    check(f"attention 1x5x4096x4096 split-KV {ns} (in-kernel merge)", lambda ns=ns: ops.attention_split(q1[:, :, :320], q1[:, :, 320:640], q1[:, :, 640:], 5, ns))
+wx = pack_xs(torch.randn(1280, 320, device=dev) / math.sqrt(320), torch.randn(1280, device=dev))
+check("gemm_xs 131072x1280x320 (X-stationary, LayerNorm)", lambda: ops.linear_xs(a, wx, ln=True))
+wg = pack_xs(torch.randn(2560, 320, device=dev) / math.sqrt(320), torch.randn(2560, device=dev), geglu=True)
+check("gemm_xs GEGLU 131072x2560x320", lambda: ops.linear_xs(a, wg, geglu=True, ln=True))
