@@ -83,19 +83,40 @@ WORKLOADS = {
 }
 
 
-def fill_synthetic_weights(model, seed: int = 0):
-    """Seeded variance-preserving random weights directly on the GPU (no pretrained SD-2.1 weights exist offline)."""
+def fill_synthetic_weights(model, seed: int = 0, q_scale: float = 1.0):
+    """Seeded variance-preserving random weights directly on the GPU (no pretrained SD-2.1 weights exist offline).
+    ``q_scale`` multiplies every query projection (to_q / to_q_ref): variance-preserving weights give attention logits of
+    unit spread, i.e. nearly FLAT softmaxes over 4096 keys -- a trained checkpoint's are peaked (``--attn-stats peaked``)."""
     g = torch.Generator(device="cuda").manual_seed(seed)
     with torch.no_grad():
         for name, p in model.named_parameters():
             if p.ndim >= 2:
                 fan_in = p[0].numel()
                 p.copy_(torch.randn(p.shape, generator=g, device="cuda") / math.sqrt(fan_in))
+                if q_scale != 1.0 and (name.endswith("to_q.weight") or name.endswith("to_q_ref.weight")):
+                    p.mul_(q_scale)
             elif name.endswith("weight"):      # every 1-D weight is a GroupNorm / LayerNorm scale
                 p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g, device="cuda"))
             else:
                 p.copy_(0.1 * torch.randn(p.shape, generator=g, device="cuda"))
     model.mark_weights_changed()
+
+
+def softmax_stats_proxy(q_scale: float, keys: int = 4096, C: int = 320, heads: int = 5, seed: int = 3):
+    """What ``q_scale`` does to a self-attention row of the 64x64 level, measured (torch, measurement glue only) on LayerNorm-like
+    inputs (unit-variance rows) through variance-preserving to_q / to_k of the synthetic initialisation: entropy of a row's
+    softmax over ``keys`` keys and the probability mass of its 8 largest entries, averaged over 256 sampled queries x heads."""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    h = torch.randn(keys, C, generator=g, device="cuda")
+    wq = torch.randn(C, C, generator=g, device="cuda") / math.sqrt(C) * q_scale
+    wk = torch.randn(C, C, generator=g, device="cuda") / math.sqrt(C)
+    q = (h[:256] @ wq.T).reshape(256, heads, C // heads).transpose(0, 1)
+    k = (h @ wk.T).reshape(keys, heads, C // heads).transpose(0, 1)
+    p = torch.softmax(q @ k.transpose(1, 2) / math.sqrt(C // heads), dim=-1)
+    ent = -(p * p.clamp_min(1e-30).log()).sum(-1).mean().item()
+    top8 = p.topk(8, dim=-1).values.sum(-1).mean().item()
+    return {"q_scale": q_scale, "entropy_nats": round(ent, 3), "uniform_entropy_nats": round(math.log(keys), 3), "top8_mass": round(top8, 4),
+            "measured_on": f"{keys} unit-variance key rows, 256 queries x {heads} heads, variance-preserving to_q / to_k (torch)"}
 
 
 def make_batch(pairs: int, rank: int, device, lat_hw: int = 64):
@@ -331,6 +352,11 @@ def main():
     ap.add_argument("--no-check", action="store_true", help="skip the determinism / cross-path output screens")
     ap.add_argument("--shapes-out", default="", help="write the per-shape kernel table of the profiled steps to this file")
     ap.add_argument("--latent", type=int, default=64, help="latent height = width (64 = 512x512 images, 96 = the reference's 768x768 default, infer.py:187)")
+    ap.add_argument("--attn-stats", choices=["flat", "peaked"], default="flat",
+                    help="flat: variance-preserving query projections (near-uniform softmaxes, the default synthetic weights); peaked: every "
+                         "to_q / to_q_ref scaled by --attn-q-scale so that a row's 8 largest probabilities hold > 90 %% of the mass, as in a "
+                         "trained checkpoint -- the attention kernel's clock and rate depend on the operand statistics")
+    ap.add_argument("--attn-q-scale", type=float, default=8.0, help="--attn-stats peaked: factor on the query projections")
     ap.add_argument("--attn-nw", type=int, default=-1, help="measurement: force log2(waves per attention workgroup)")
     ap.add_argument("--debug-flags", type=int, default=0, help="measurement: mvd_debug_set_flags bits")
     ap.add_argument("--launch-dry-run", action="store_true",
@@ -400,8 +426,9 @@ def main():
     model.use_hip_graph = args.graph
     if args.global_ref_stats:
         model.reference_stats_group = True
+    q_scale = args.attn_q_scale if args.attn_stats == "peaked" else 1.0
     if rank == 0:
-        fill_synthetic_weights(model, 0)
+        fill_synthetic_weights(model, 0, q_scale)
     else:
         with torch.no_grad():
             for p in model.parameters():
@@ -537,7 +564,8 @@ def main():
             "config": {"workload": f"{args.workload}: {desc}", "pairs_per_gpu": pairs, "global_pairs": total_pairs,
                        "latent": f"{args.latent}x{args.latent}x4", "image": f"{8 * args.latent}x{8 * args.latent}", "text_tokens": 77, "forward": forward_kind, "hip_graph": bool(args.graph), "q2_statistics": "global" if args.global_ref_stats else "replica-local",
                        "gflop_per_pair": round(flops_pair / 1e9, 2), "parallelism": f"dp{world} (pairs sharded by object)",
-                       "weights": "synthetic seeded, SD2.1 shapes (865.9M UNet x2 + 99.2M adapter + 19.1M camera)"},
+                       "weights": "synthetic seeded, SD2.1 shapes (865.9M UNet x2 + 99.2M adapter + 19.1M camera)",
+                       "attn_stats": {"mode": args.attn_stats, **softmax_stats_proxy(q_scale)}},
             "roofline": roofline, "cpu_baseline": cpu, "output_check": check, "kernel_src_sha": kernel_source_sha(),
             "gpu_ms_per_step_events": round(gpu_ms / args.steps, 3),
             "weight_bytes_bf16_packed": weight_bytes,

@@ -396,9 +396,45 @@ int mvd_launch_conv_in(const bf16_t* x, int batch, int h, int w, int cin, const 
   return check("conv_in");
 }
 
+#ifdef MVD_PROBE
+#include <stdio.h>
+#include <unistd.h>
+#include "probe/conv_out4.inc"
+__global__ void word_sum_kernel(const unsigned* __restrict__ p, long n, unsigned long long* out) {
+  unsigned long long s = 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s += (unsigned long long)p[i] * (unsigned long long)((i & 1023) + 1);
+  atomicAdd(out, s);
+}
+#endif
+
 int mvd_launch_conv_out(const bf16_t* x, int batch, int h, int w, int c, const bf16_t* wt, const float* bias, int cout,
                         float* y, hipStream_t s) {
   if (!x || !y || !wt || !bias || batch <= 0 || h <= 0 || w <= 0 || (c % 8) || cout <= 0 || cout > 8) { mvd_set_error("conv_out: bad arguments"); return -1; }
+#ifdef MVD_PROBE
+  if (MVD_ENV_INT("MVD_CONV_OUT4", 0)) {          // diagnosis of the reverted four-pixel form (probe builds only)
+    const long quads = (long)batch * h * ((w + 3) / 4);
+    hipLaunchKernelGGL(conv_out4_kernel, dim3(nblk(quads, 4)), dim3(256), 0, s, x, batch, h, w, c, wt, bias, cout, y);
+    if (MVD_ENV_INT("MVD_CONV_OUT_HASH", 0)) {
+      // word sums of the INPUT, of the four-pixel kernel's output, and of the one-pixel kernel's output on the same input
+      // (to a scratch buffer): which of them differs between two forwards of the same arguments?
+      static unsigned long long* dsum = nullptr; static float* y1 = nullptr; static size_t y1n = 0;
+      const size_t on = (size_t)batch * cout * h * w;
+      if (!dsum) (void)hipMalloc(&dsum, 3 * sizeof(unsigned long long));
+      if (y1n < on) { if (y1) (void)hipFree(y1); (void)hipMalloc(&y1, on * sizeof(float)); y1n = on; }
+      (void)hipMemsetAsync(dsum, 0, 3 * sizeof(unsigned long long), s);
+      const long pix1 = (long)batch * h * w;
+      hipLaunchKernelGGL(conv_out_kernel, dim3(nblk(pix1, 4)), dim3(256), 0, s, x, batch, h, w, c, wt, bias, cout, y1);
+      hipLaunchKernelGGL(word_sum_kernel, dim3(1024), dim3(256), 0, s, reinterpret_cast<const unsigned*>(x), (long)((size_t)batch * h * w * c / 2), dsum);
+      hipLaunchKernelGGL(word_sum_kernel, dim3(1024), dim3(256), 0, s, reinterpret_cast<const unsigned*>(y), (long)on, dsum + 1);
+      hipLaunchKernelGGL(word_sum_kernel, dim3(1024), dim3(256), 0, s, reinterpret_cast<const unsigned*>(y1), (long)on, dsum + 2);
+      unsigned long long hs[3] = {0, 0, 0};
+      (void)hipMemcpyAsync(hs, dsum, sizeof(hs), hipMemcpyDeviceToHost, s);
+      (void)hipStreamSynchronize(s);
+      fprintf(stderr, "conv_out hash pid %d: input %016llx  out(4-pixel) %016llx  out(1-pixel, same input) %016llx\n", (int)getpid(), hs[0], hs[1], hs[2]);
+    }
+    return check("conv_out4");
+  }
+#endif
   const long pix = (long)batch * h * w;
   hipLaunchKernelGGL(conv_out_kernel, dim3(nblk(pix, 4)), dim3(256), 0, s, x, batch, h, w, c, wt, bias, cout, y);
   return check("conv_out");
