@@ -421,8 +421,11 @@ __global__ __launch_bounds__(64 * NW, SPLIT ? 3 : (VSUM ? 4 : ((NW == 4 && NSUB 
   };   // run_tiles
   if constexpr (LAZY) {
     run_tiles(std::false_type{});
-    // lanes 0..15 hold the complete denominators of queries n and n + 16 (see lacc): anything not comfortably finite -> redo checked
-    const int bad = (lane < 16 && !(lacc[0] < 1.0e30f && lacc[1] < 1.0e30f)) ? 1 : 0;
+    // lanes 0..15 hold the complete denominators of queries n and n + 16 (see lacc): anything beyond 2^64 -> redo checked.  (The
+    // bound also keeps the UNCHECKED accumulators finite: |O| <= l max|v| < 2^64 max|v|, so O overflows fp32 only for |v| > 2^63;
+    // with the former bound of 1e30 a value of 1e9 behind a score 2^90 above the first tile's maximum gave l = 2^90 -- accepted --
+    // and O = inf.  ADVICE r3.)
+    const int bad = (lane < 16 && !(lacc[0] < 1.8446744e19f && lacc[1] < 1.8446744e19f)) ? 1 : 0;
     if (__syncthreads_or(bad)) run_tiles(std::true_type{});
   } else {
     run_tiles(std::true_type{});

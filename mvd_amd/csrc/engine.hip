@@ -203,12 +203,17 @@ struct Ctx {
     e->prof_recs.push_back({cls, flops, bytes, e0, e1, e->prof_M, e->prof_N, e->prof_K, e->prof_tag});
     return r;
   }
+  // whether the small-M kernels (gemm_sm.hip) are in use at all: ONE predicate for Ctx::gemm's route and for ln_linear's
+  // "the fold is available through them" test (a kill switch must make the forward fall back, not fail)
+  static bool sm_enabled() {
+    static const bool use_sm = MVD_ENV_INT("MVD_GEMM_SM", 1) != 0;
+    return use_sm && !(g_debug_flags & 4);
+  }
   int gemm(MvdGemmArgs& g) {
     if (err) return err;
     // small problems (one image's feature maps): the latency-oriented kernels of gemm_sm.hip, split-K combined in the kernel
-    static const bool use_sm = MVD_ENV_INT("MVD_GEMM_SM", 1) != 0;
     int sm_tile = 0, sm_ns = 0, sm_S = 1;
-    if (use_sm && !(g_debug_flags & 4) && mvd_gemm_sm_plan(g, &sm_tile, &sm_ns, &sm_S)) {
+    if (sm_enabled() && mvd_gemm_sm_plan(g, &sm_tile, &sm_ns, &sm_S)) {
       if (g_debug_flags & 2) sm_S = 1;
       const size_t mark = e->tmp.off;
       if (sm_S > 1) {
@@ -308,7 +313,7 @@ struct Ctx {
       static const float dummy = 0.f;
       t.ln_c1 = &dummy; t.bias = &dummy; t.W = reinterpret_cast<const bf16_t*>(&dummy);
       int a_, b_, c_;
-      return !(g_debug_flags & 5) && mvd_gemm_sm_plan(t, &a_, &b_, &c_);
+      return sm_enabled() && !(g_debug_flags & 1) && mvd_gemm_sm_plan(t, &a_, &b_, &c_);
     };
     if (use_fold && !dry && has(slot + ".wf") && has(slot + ".cf") && (mvd_gemm_ln_fold_ok(g) || sm_fold_ok())) {
       const float* cf = WF(slot + ".cf", 2 * n_full);
@@ -816,7 +821,7 @@ int setup_tile_counters(mvd_engine* e, unsigned int* block, hipStream_t s, bool 
   return 0;
 }
 
-int forward_impl(mvd_engine* e, const mvd_forward_args_t& a, hipStream_t s, bool dry) {
+int forward_body(mvd_engine* e, const mvd_forward_args_t& a, hipStream_t s, bool dry) {
   const mvd_config_t& cfg = e->cfg;
   if (a.batch <= 0 || a.height <= 0 || a.width <= 0 || a.text_len <= 0) { mvd_set_error("forward: bad shape"); return -1; }
   const int div = 1 << (cfg.num_levels - 1);
@@ -947,6 +952,18 @@ int forward_impl(mvd_engine* e, const mvd_forward_args_t& a, hipStream_t s, bool
   if (c.err) return c.err;
   if (!dry && (e->tmp.high + e->act.high > (size_t)e->ws_bytes)) { mvd_set_error("forward: workspace too small"); return -4; }
   return 0;
+}
+
+// Every exit of a forward that forked the side stream joins it: an error return between fork and join (a failed check in the
+// camera path or a pass, a workspace that is too small) must not leave the encoder pass writing the reference cache and the
+// activation arena while the caller frees or reuses them.  The success path has joined with an event already.
+int forward_impl(mvd_engine* e, const mvd_forward_args_t& a, hipStream_t s, bool dry) {
+  const int r = forward_body(e, a, s, dry);
+  if (e->dual_now) {
+    if (e->side) (void)hipStreamSynchronize(e->side);      // error path only: the cheap join is not worth an event here
+    e->dual_now = false;
+  }
+  return r;
 }
 
 // Second half of the global-statistics path: normalise the kept raw features with the merged per-pixel (mean, k) and

@@ -259,6 +259,22 @@ def test_bf16_drift_over_a_real_schedule(tiny, steps, gs, final_tol, growth):
         assert errs[i] <= growth * errs[i - 1] + 2e-3, (i, errs[i - 1], errs[i])
 
 
+def test_small_m_kill_switch_falls_back_instead_of_failing():
+    """with the small-M kernels switched off (mvd_debug_set_flags bit 2) a batch-1 forward at SD-2.1 widths must fall
+    back -- ln_kernel + the general GEMMs at C = 1280, where the ping-pong LayerNorm fold does not apply -- not stop with
+    "LayerNorm fold not available".  32 x 32 latents keep the CPU oracle short; the base UNet only (no adapter, no camera)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mvd_amd import _lib as L
+    from tests.parity_util import run_tiny_parity
+    L.lib().mvd_debug_set_flags(4)
+    try:
+        stats = run_tiny_parity(batch=1, verbose=True, cfg_name="sd21", hw=32, text_len=77, cam=False, img=False)
+    finally:
+        L.lib().mvd_debug_set_flags(0)
+    assert stats["finite"] and stats["rel_l2"] <= TOL_L2 and stats["max_rel"] <= TOL_MAX, stats
+
+
 def test_sd21_full_size_parity_768():
     """The reference's own default: 768 x 768 images = 96 x 96 latents (infer.py:187, config/train_config.yaml sample_size 96), full
     SD-2.1 shapes, B = 1, camera FiLM + cross-view adapter, cold forward: 9216 tokens at the first level (the split-KV attention,

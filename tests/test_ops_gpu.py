@@ -525,6 +525,28 @@ def test_attention_running_max_fallback(ops, nq, nk, jump_at, nsplit):
     close(got, want, tol=2 ** -6, what=f"attention, scores jumping at key {jump_at} of {nk}")
 
 
+def test_attention_running_max_fallback_when_only_o_would_overflow(ops):
+    """the overflow can sit in the UNCHECKED accumulators, not in the denominators.  Scores of the later keys lie ~2^90
+    (exp2 domain) above the first tile's maximum -- the denominators reach 2^90, finite and below the former acceptance bound of
+    1e30 -- and those keys' values are ~3e9: l * |v| = 4e36 * nk overflows fp32.  The bound of 2^64 on l sends such a workgroup
+    to the checked loop; the result is the plain softmax average (finite, ~3e9)."""
+    B, heads, nq, nk, jump_at = 1, 2, 128, 512, 64
+    C = heads * 64
+    g = torch.Generator().manual_seed(9)
+    q = 0.02 * torch.randn(B, nq, C, generator=g) + 1.0
+    k = 0.02 * torch.randn(B, nk, C, generator=g)
+    k[:, :jump_at] -= 0.703125                # q.k = 64 * (-0.703) = -45  |  +45 behind the jump: 90 apart
+    k[:, jump_at:] += 0.703125
+    v = torch.randn(B, nk, C, generator=g)
+    v[:, jump_at:] *= 3.0e9
+    qs, k, v = q.to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16)
+    sp = lambda t, n: t.double().view(B, n, heads, 64).transpose(1, 2)  # noqa: E731
+    want = F.scaled_dot_product_attention(sp(qs, nq) * 0.6931471805599453, sp(k, nk), sp(v, nk), scale=1.0)
+    want = want.transpose(1, 2).reshape(B, nq, C).float()
+    got = ops.attention(qs.cuda(), k.cuda(), v.cuda(), heads, scale=0.0)
+    close(got, want, tol=2 ** -6, what="attention, overflow in O only")
+
+
 @pytest.mark.parametrize("B,heads,nq,nk,nsplit,shift", [
     (1, 5, 4096, 4096, 4, 0.0),        # the 64x64-level self-attention of a batch-1 forward
     (1, 10, 1024, 1024, 4, 0.0), (1, 10, 1024, 1024, 2, 0.0),
