@@ -6,7 +6,7 @@ import torch
 from mvd_amd import ops
 rnd = lambda *s: (torch.randn(*s, device="cuda") * 0.5).to(torch.bfloat16)
 B = 32
-which = os.environ.get("PMC_OPS", "attn,conv,lin,geglu").split(",")
+which = os.environ.get("PMC_OPS", "attn,conv,lin,geglu,xs").split(",")
 if "attn" in which:
     q, k, v = rnd(B, 4096, 320), rnd(B, 4096, 320), rnd(B, 4096, 320)
     for _ in range(3): ops.attention(q, k, v, 5, scale=0.0)      # the engine's form: prescaled q, LDS-DMA staging, dot2c denominators
@@ -23,4 +23,12 @@ if "lin" in which:
 if "geglu" in which:
     a, w = rnd(131072, 320), rnd(2560, 320)
     for _ in range(3): ops.linear(a, w, geglu=True, force_cfg=6)
+if "xs" in which:      # the X-stationary kernels (gemm_xs.hip) at the 64x64-level shapes: N = 320 + residual, LayerNorm N = 1280, GEGLU
+    import math
+    from mvd_amd.packing import pack_xs
+    a = rnd(131072, 320)
+    for n, geglu, ln, res in ((320, False, False, True), (1280, False, True, False), (2560, True, True, False)):
+        wp = pack_xs(torch.randn(n, 320, device="cuda") / math.sqrt(320), torch.randn(n, device="cuda"), geglu=geglu)
+        r = rnd(131072, n) if res else None
+        for _ in range(3): ops.linear_xs(a, wp, geglu=geglu, ln=ln, res=r)
 torch.cuda.synchronize()
