@@ -6,9 +6,11 @@
 # GRBM_GUI_ACTIVE pass (shader clock under load, tools/clock_summary.py) and the SQ-counter passes on isolated launches.
 set -e -o pipefail
 TAG=${1:-r04}
+STAGE=${2:-ABC}          # A: PMC traffic + the headline line + rocprof stats + sustained + peaked; B: batch 1, 768^2, e2e; C: SQ counters
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+if [[ $STAGE == *A* ]]; then
 # the PMC traffic passes FIRST: bench.py quotes roofline.traffic from profiles/<tag>_pmc_hbm_traffic.json (stamped with the kernel
 # source hash), so the file has to be in place -- in this box's copy of the tree -- before the bench line is produced
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-check > /dev/null 2> $OUT/pmc_fetch.err
@@ -37,6 +39,11 @@ cat $OUT/frac_from_stats.txt
 echo "--- sustained: 400 steps"
 python bench.py --steps 400 --warmup 5 --no-cpu-baseline > $OUT/bench_cfg4_400steps.json 2> /dev/null
 python -c "import json;a=json.load(open('$OUT/bench_cfg4.json'));b=json.load(open('$OUT/bench_cfg4_400steps.json'));print('20 steps', a['value'], '400 steps', b['value'], 'ratio', round(b['value']/a['value'],4))" | tee $OUT/sustained.txt
+echo "--- peaked softmaxes (--attn-stats peaked: query projections x 8)"
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --attn-stats peaked > $OUT/bench_cfg4_attn_peaked.json 2> /dev/null
+python -c "import json;a=json.load(open('$OUT/bench_cfg4.json'));b=json.load(open('$OUT/bench_cfg4_attn_peaked.json'));print('flat', a['value'], a['roofline']['kernel'], a['roofline']['achieved'], a['config']['attn_stats']);print('peaked', b['value'], b['roofline']['kernel'], b['roofline']['achieved'], b['config']['attn_stats'])" | tee $OUT/attn_stats.txt
+fi
+if [[ $STAGE == *B* ]]; then
 echo "--- batch 1"
 python bench.py --workload cfg2 --steps 50 --warmup 5 --no-cpu-baseline --shapes-out $OUT/shapes_cfg2.txt > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof2 -o stats -- python3 bench.py --workload cfg2 --steps 25 --warmup 1 --no-cpu-baseline --no-check --no-profile > $OUT/bench_cfg2_under_rocprof.json 2> $OUT/rocprof2.err
@@ -55,8 +62,10 @@ python bench.py --workload e2e --steps 5 --warmup 1 > $OUT/bench_e2e_512.json 2>
 python bench.py --workload e2e --steps 5 --warmup 1 --cached --no-cpu-baseline > $OUT/bench_e2e_512_cached.json 2> /dev/null
 python bench.py --workload e2e --latent 96 --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_e2e_768.json 2> /dev/null
 python bench.py --workload e2e --latent 96 --steps 5 --warmup 1 --cached --no-cpu-baseline > $OUT/bench_e2e_768_cached.json 2> /dev/null
-for f in cfg2 cfg3 cfg3_one_stream cfg3_cached cfg4 cfg4_cached cfg4_one_stream cfg4_two_streams_single_stream_launch_policy cfg2_latent96 cfg3_latent96 cfg4_latent96; do python -c "import json;d=json.load(open('$OUT/bench_$f.json'));print('$f', d['ms_per_step'], d['value'])"; done
+for f in cfg2 cfg3 cfg3_one_stream cfg3_cached cfg4 cfg4_cached cfg4_one_stream cfg4_two_streams_single_stream_launch_policy cfg2_latent96 cfg3_latent96 cfg4_latent96; do python -c "import json;d=json.load(open('$OUT/bench_$f.json'));print('$f', d['ms_per_step'], d['value'])" || true; done
 for f in e2e_512 e2e_512_cached e2e_768 e2e_768_cached; do python -c "import json;d=json.load(open('$OUT/bench_$f.json'));print('$f', d['seconds_per_image'], d['phases_ms'])"; done
+fi
+if [[ $STAGE == *C* ]]; then
 # SQ counters on isolated launches of the hot kernels (tools/pmc_ops.py), a few counters per pass
 i=0
 for CS in "FETCH_SIZE" "WRITE_SIZE" "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" "SQ_INSTS_VMEM SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_WAVES"; do
@@ -65,5 +74,6 @@ for CS in "FETCH_SIZE" "WRITE_SIZE" "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_
 done
 python tools/pmc_ops_summary.py $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_sq3 $OUT/pmc_sq4 $OUT/pmc_sq5 > $OUT/pmc_sq_counters.txt || true
 rm -rf $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_sq3 $OUT/pmc_sq4 $OUT/pmc_sq5
+fi
 # the raw counter csvs are large: keep the summaries only
 ls -la $OUT
