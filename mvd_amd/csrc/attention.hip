@@ -530,6 +530,40 @@ __global__ __launch_bounds__(64 * NW, SPLIT ? 3 : (VSUM ? 4 : ((NW == 4 && NSUB 
       return;
     }
   }
+#ifndef MVD_ATTN_ROW_STORES      // (A/B builds: the round-3 epilogue)
+  if constexpr (DMA && TILE_BYTES * 4 >= NW * 4096) {
+    // A lane holds 16 pieces of 4 dims of ITS query's row: stored as they stand, each of 8 store instructions touches 32 rows x 2
+    // pieces of 8 bytes -- and a vector-memory instruction's issue cost grows with the lines it touches (~460 cycles per such
+    // store with eight waves storing, which also holds up the K/V LDS-DMAs of the workgroups still in their loops; measured on
+    // the X-stationary GEMM).  An output row of one head is exactly one 128-byte line: the wave writes its
+    // 32 x 128 bytes into the (now dead: the loop ends behind a barrier) K/V stages, 16-byte chunk c of row r at c ^ (r & 7), reads
+    // [8 rows x 128 B] per instruction and stores WHOLE lines: 4 instructions of 8 lines instead of 8 of 32.
+    // (the kernel sits at 128 registers: every address of this epilogue is derived HERE from an opaque copy of the lane id, so
+    //  that nothing of it is hoisted above the tile loop and spilled)
+    int el = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(el));
+    const int elq = el & 31;
+    const int wbase = wave * 4096 + elq * 128 + 8 * (el >> 5), wswz = (elq & 7) << 4;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const u32x2 w0 = {pack2bf(o0[4 * g] * inv, o0[4 * g + 1] * inv), pack2bf(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv)};
+      const u32x2 w1 = {pack2bf(o1[4 * g] * inv, o1[4 * g + 1] * inv), pack2bf(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv)};
+      *reinterpret_cast<u32x2*>(smem + wbase + ((g << 4) ^ wswz)) = w0;              // dims 8 g + 4 lh .. + 3
+      *reinterpret_cast<u32x2*>(smem + wbase + (((4 + g) << 4) ^ wswz)) = w1;        // dims 32 + 8 g + 4 lh ..
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (LDS operations of one wave execute in order; nobody else touches this 4 KB)
+    const int rr = el >> 3, rc = el & 7;
+    const int rbase = wave * 4096 + rr * 128 + ((rc ^ rr) << 4);                      // (row & 7 == rr for every j)
+    const int q0 = qblk0 + wave * 32 + rr;
+    bf16_t* orow = op + (size_t)q0 * P.ldo + rc * 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(smem + rbase + j * 1024);
+      if (q0 + 8 * j < nq) *reinterpret_cast<u32x4*>(orow + (size_t)(8 * j) * P.ldo) = v;
+    }
+    return;
+  }
+#endif
   if (qrow < nq) {
     bf16_t* orow = op + (size_t)qrow * P.ldo;
 #pragma unroll
