@@ -140,6 +140,9 @@ __global__ __launch_bounds__(64 * NW, SPLIT ? 3 : (VSUM ? 4 : ((NW == 4 && NSUB 
   const int qrow = qblk0 + wave * 32 + lq;
   const int qrow_c = qrow < nq ? qrow : nq - 1;
   bf16x8 qf[4];
+  // (Loading Q coalesced -- [8 rows x 128 B] per instruction through the still empty stage-1 buffers, read back as fragments --
+  //  was measured in round 4: 516.8 vs 517.5 fwd/s, attention class 15.68 vs 15.72 ms: nothing; four loads per workgroup pass
+  //  are not what the O stores were.)
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks)
     qf[ks] = *reinterpret_cast<const bf16x8*>(qp + (size_t)qrow_c * P.ldq + ks * 16 + lh * 8);
@@ -543,7 +546,10 @@ __global__ __launch_bounds__(64 * NW, SPLIT ? 3 : (VSUM ? 4 : ((NW == 4 && NSUB 
     int el = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     asm volatile("" : "+v"(el));
     const int elq = el & 31;
-    const int wbase = wave * 4096 + elq * 128 + 8 * (el >> 5), wswz = (elq & 7) << 4;
+    int etid = tid;
+    asm volatile("" : "+v"(etid));
+    const int ew = __builtin_amdgcn_readfirstlane(etid >> 6);          // the wave index again, as a scalar, derived here
+    const int wbase = ew * 4096 + elq * 128 + 8 * (el >> 5), wswz = (elq & 7) << 4;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const u32x2 w0 = {pack2bf(o0[4 * g] * inv, o0[4 * g + 1] * inv), pack2bf(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv)};
@@ -553,8 +559,8 @@ __global__ __launch_bounds__(64 * NW, SPLIT ? 3 : (VSUM ? 4 : ((NW == 4 && NSUB 
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (LDS operations of one wave execute in order; nobody else touches this 4 KB)
     const int rr = el >> 3, rc = el & 7;
-    const int rbase = wave * 4096 + rr * 128 + ((rc ^ rr) << 4);                      // (row & 7 == rr for every j)
-    const int q0 = qblk0 + wave * 32 + rr;
+    const int rbase = ew * 4096 + rr * 128 + ((rc ^ rr) << 4);                        // (row & 7 == rr for every j)
+    const int q0 = qblk0 + ew * 32 + rr;
     bf16_t* orow = op + (size_t)q0 * P.ldo + rc * 8;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
