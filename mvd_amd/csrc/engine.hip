@@ -267,11 +267,14 @@ struct Ctx {
   int try_xs(const bf16_t* x, int K, int M, const std::string& slot, int64_t n_full, int N, bool geglu, bool ln,
              const bf16_t* res, int ldres, void* out, int ldo, int set_override = -1) {
     if (err) return err;
-    if (dry || (g_debug_flags & 128) || K != 320 || M < 32768 || slot.empty() || !has(slot, set_override)) return 0;
+    if (dry || (g_debug_flags & 128) || K != 320 || slot.empty() || !has(slot, set_override)) return 0;
     MvdXsArgs a; memset(&a, 0, sizeof(a));
     a.x = x; a.ldx = K; a.M = M; a.K = K; a.units = N / 32; a.geglu = geglu; a.ln = ln; a.ln_eps = 1e-5f;
     a.res = res; a.ldres = ldres; a.out = (bf16_t*)out; a.ldo = ldo;
     if (N % 64 || !mvd_gemm_xs_applicable(a)) return 0;
+    // two workgroups per CU or nothing: with fewer work items than ~1.75 per CU (N = 320 cannot be split into column parts: five
+    // store groups) the ping-pong / lock-step tiles fill the chip better
+    if ((long)((M + 255) / 256) * mvd_gemm_xs_pick_csplit(a) < 448) return 0;
     a.w = WB(slot, (n_full / 32) * 21 * 512, set_override);
     if (!a.w) return err;
     e->prof_M = M; e->prof_N = N; e->prof_K = K; e->prof_tag = geglu * 10 + (ln ? 1 : 0);
