@@ -57,7 +57,10 @@ MVD_DEVINL void xs_store16(u32x4 v, __amdgpu_buffer_rsrc_t rsrc, int voff, int s
 
 template <int KS, bool GEGLU, bool RES, bool LN>
 __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const MvdXsArgs a) {
-  constexpr int NW = 4, RT = 2, NS = 3;
+  // ring depth: 3 units (GEGLU: 2 -- its store staging holds both row tiles of a 128-byte group, 8 KB per wave, and two workgroups
+  // share 160 KB; a unit's LDS-DMAs are then issued one unit ahead instead of two: ~4000 cycles of cover for an L2 hit)
+  constexpr int NW = 4, RT = 2, NS = GEGLU ? 2 : 3;
+  constexpr int STG = GEGLU ? 8192 : 4096;              // store staging per wave
   constexpr int UNIT = (KS + 1) * 1024;                 // KS operand k-steps + the bias k-step
   constexpr int P = KS / NW;                            // 1 KB DMA pieces per wave and unit (+ one 256-byte piece of the bias k-step)
   static_assert(KS % NW == 0 && !(GEGLU && RES) && !(RES && LN), "shape of the instantiations");
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const MvdXsArgs a) {
     xs_dma4(rs_w, dst + KS * 1024 + wave * 256, (unsigned)lane * 4u, so + (unsigned)(KS * 1024 + wave * 256));
   };
   issue_unit(0, 0);
-  if (nit > 1) issue_unit(1, 1);
+  if (NS == 3 && nit > 1) issue_unit(1, 1);
 
   // ---- the wave's 64 tokens -> B-operand fragments (rows >= M lie beyond num_records and read as zeros)
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.x), 0, (int)((size_t)a.M * a.ldx * 2), 0x00020000);
@@ -167,16 +170,22 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const MvdXsArgs a) {
   // still reads unit it - 1, whose stage takes unit it + 2
   auto top = [&](int it, int stage) {
     XS_STAMP(4);
+    // counted wait for this wave's pieces of unit `it`: everything it issued BEHIND them may still be in flight.
+    //  three stages: unit it's DMAs were issued at the top of iteration it - 2 -> behind them: that iteration's epilogue, the DMAs
+    //    of unit it + 1 (none in the last iteration), the epilogue of iteration it - 1; an epilogue runs every second unit;
+    //  two stages (GEGLU): issued at the top of iteration it - 1 -> behind them: that iteration's epilogue only -- 8 stores behind
+    //    every fourth unit (gate | value | gate | value = one 128-byte store group).
     if (it == 0) XS_WAIT_VM(0);
-    else if (it == nit - 1) { if (GEGLU) XS_WAIT_VM(4); else if (RES) XS_WAIT_VM(16); else XS_WAIT_VM(8); }              // 2 E
-    else { if (GEGLU) XS_WAIT_VM(10); else if (RES) XS_WAIT_VM(22); else XS_WAIT_VM(14); }                               // 2 E + P + 1
-    static_assert(P + 1 == 6 && (GEGLU || 2 * E == (RES ? 16 : 8)), "the counted waits above are written for these instantiations");
+    else if constexpr (GEGLU) { if ((it & 3) == 0) XS_WAIT_VM(8); else XS_WAIT_VM(0); }
+    else if (it == nit - 1) { if (RES) XS_WAIT_VM(16); else XS_WAIT_VM(8); }                    // 2 E
+    else { if (RES) XS_WAIT_VM(22); else XS_WAIT_VM(14); }                                      // 2 E + P + 1
+    static_assert(P + 1 == 6 && 2 * E == (RES ? 16 : 8), "the counted waits above are written for these instantiations");
     __builtin_amdgcn_sched_barrier(0);
     XS_STAMP(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     XS_STAMP(1);
-    if (it + 2 < nit) issue_unit(it + 2, stage >= 1 ? stage - 1 : 2);
+    if (it + NS - 1 < nit) issue_unit(it + NS - 1, NS == 2 ? (stage ^ 1) : (stage >= 1 ? stage - 1 : 2));
     __builtin_amdgcn_sched_barrier(0);
     XS_STAMP(2);
   };
@@ -254,24 +263,24 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const MvdXsArgs a) {
   // each lane writes its 16-byte chunks at [token][chunk ^ swizzle(token)], reads back [8 (16) tokens x 8 (4) chunks] per
   // instruction and stores WHOLE 128-byte (64-byte) row segments: 8 (16) lines per store instead of 32.  LDS operations of
   // one wave execute in order, so the area needs no barrier; both the ds_write_b128 and the ds_read_b128 are conflict free.
-  constexpr int LB = GEGLU ? 64 : 128, CPR = LB / 16, RPI = 64 / CPR, NJ = 32 / RPI;   // chunks per row, rows per instruction, instructions per row tile
-  unsigned char* const stg = smem + NS * UNIT + wave * 4096;
-  const int sw_w = GEGLU ? ((r >> 1) & 3) : (r & 7);                 // swizzle of the lane's own token row
+  constexpr int LB = 128, CPR = 8, RPI = 8, NJ = 4;                    // bytes per staged row, chunks per row, rows per instruction, instructions per row tile
+  unsigned char* const stg = smem + NS * UNIT + wave * STG;           // plain: one row tile at a time (4 KB); GEGLU: both (8 KB)
+  const int sw_w = r & 7;                                              // swizzle of the lane's own token row
   const int rd_row = lane / CPR, rd_c = lane % CPR;                   // the (row, chunk) this lane reads back (+ RPI rows per j)
   int vo_l[RT];
 #pragma unroll
   for (int t = 0; t < RT; ++t) vo_l[t] = (row_w + t * 32 + rd_row) * a.ldo * 2 + rd_c * 16;
   const int so_j = RPI * a.ldo * 2;                                    // (scalar) byte step between a lane's rows
-  auto stage_chunk = [&](int chunk, u32x4 v) {
-    *reinterpret_cast<u32x4*>(stg + r * LB + ((chunk ^ sw_w) << 4)) = v;
+  auto stage_chunk = [&](int t, int chunk, u32x4 v) {                  // t: which 4 KB of the staging area (plain: always 0)
+    *reinterpret_cast<u32x4*>(stg + t * 4096 + r * LB + ((chunk ^ sw_w) << 4)) = v;
   };
-  auto flush_rows = [&](int t, int so) {
+  auto flush_rows = [&](int t, int tbuf, int so) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     u32x4 v[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int row = j * RPI + rd_row;
-      v[j] = *reinterpret_cast<const u32x4*>(stg + row * LB + ((rd_c ^ (GEGLU ? ((row >> 1) & 3) : (row & 7))) << 4));
+      v[j] = *reinterpret_cast<const u32x4*>(stg + tbuf * 4096 + row * LB + ((rd_c ^ (row & 7)) << 4));
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -295,19 +304,23 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const MvdXsArgs a) {
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
       if (RES) { add_res(v0[t], t, g * 128); add_res(v1[t], t, g * 128 + 64); }
-      stage_chunk(2 * h, pack8(v0[t], 0)); stage_chunk(2 * h + 1, pack8(v0[t], 1));
-      stage_chunk(4 + 2 * h, pack8(v1[t], 0)); stage_chunk(4 + 2 * h + 1, pack8(v1[t], 1));
-      flush_rows(t, g * 128);
+      stage_chunk(0, 2 * h, pack8(v0[t], 0)); stage_chunk(0, 2 * h + 1, pack8(v0[t], 1));
+      stage_chunk(0, 4 + 2 * h, pack8(v1[t], 0)); stage_chunk(0, 4 + 2 * h + 1, pack8(v1[t], 1));
+      flush_rows(t, 0, g * 128);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
-  // GEGLU: one 32-channel output tile
-  auto store_one = [&](int tile, const f32x16 (&v)[RT]) {
+  // GEGLU: the 32-channel output tile `half` (0 / 1) of a 128-byte group goes to the staging area; the second one flushes both
+  // row tiles as whole lines.  (Stored per tile as 64-byte row pieces the L2 evicted half-written lines: 553 MB of traffic per
+  // launch for 419 algorithmic.)
+  auto stage_tile = [&](int half, const f32x16 (&v)[RT]) {
 #pragma unroll
-    for (int t = 0; t < RT; ++t) {
-      stage_chunk(2 * h, pack8(v[t], 0)); stage_chunk(2 * h + 1, pack8(v[t], 1));
-      flush_rows(t, tile * 64);
-    }
+    for (int t = 0; t < RT; ++t) { stage_chunk(t, 4 * half + 2 * h, pack8(v[t], 0)); stage_chunk(t, 4 * half + 2 * h + 1, pack8(v[t], 1)); }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto flush_group = [&](int g) {
+#pragma unroll
+    for (int t = 0; t < RT; ++t) flush_rows(t, t, g * 128);
     __builtin_amdgcn_sched_barrier(0);
   };
 
@@ -329,8 +342,9 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const MvdXsArgs a) {
       store_pair((u0 + it) >> 1, acc0, acc1);
     }
   } else {
+    // four units = one 128-byte store group: gate | value of output tile 2 g, gate | value of tile 2 g + 1 (host: units per part % 4 == 0)
     for (int it = 0; it < nit; it += 2) {
-      {   // gate unit: its raw accumulators wait in gg
+      {   // gate unit: its raw accumulators wait in gs
         top(it, stage);
         f32x16 gg[RT];
         multiply(stage, gg, gs, false);
@@ -348,7 +362,8 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const MvdXsArgs a) {
         for (int t = 0; t < RT; ++t)
 #pragma unroll
           for (int q = 0; q < 16; ++q) acc[t][q] *= gs[t * 16 + q];
-        store_one((u0 + it) >> 1, acc);
+        stage_tile((it >> 1) & 1, acc);
+        if (it & 2) flush_group((u0 + it) >> 2);
         stage = stage == NS - 1 ? 0 : stage + 1;
       }
     }
@@ -366,7 +381,7 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const MvdXsArgs a) {
 
 template <int KS, bool GEGLU, bool RES, bool LN>
 int launch_xs(const MvdXsArgs& a, hipStream_t s) {
-  constexpr int LDS_BYTES = 3 * (KS + 1) * 1024 + 4 * 4096;     // ring + the per-wave store staging
+  constexpr int LDS_BYTES = (GEGLU ? 2 : 3) * (KS + 1) * 1024 + 4 * (GEGLU ? 8192 : 4096);     // ring + the per-wave store staging
   static bool init[16] = {};                            // per device
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -394,7 +409,7 @@ int launch_xs(const MvdXsArgs& a, hipStream_t s) {
 bool mvd_gemm_xs_applicable(const MvdXsArgs& a) {
   const size_t lim = (size_t)1 << 31;
   if (a.K != 320 || a.units <= 0 || a.M <= 0) return false;
-  if (a.units & 1) return false;                        // store groups are unit pairs (GEGLU: gate | value)
+  if (a.units % (a.geglu ? 4 : 2)) return false;        // store groups: two units = 128 bytes per token (GEGLU: gate | value | gate | value)
   if ((a.geglu || a.ln) && a.res) return false;
   if ((size_t)(a.M + 256) * a.ldx * 2 >= lim || (size_t)(a.M + 256) * a.ldo * 2 >= lim) return false;
   if (a.res && (size_t)(a.M + 256) * a.ldres * 2 >= lim) return false;
@@ -406,7 +421,7 @@ bool mvd_gemm_xs_applicable(const MvdXsArgs& a) {
 // column split: enough work items for two rounds of 512 resident workgroups, parts of whole (GEGLU: pairs of) units
 int mvd_gemm_xs_pick_csplit(const MvdXsArgs& a) {
   const int nrb = (a.M + 255) / 256;
-  const int groups = a.units / 2;
+  const int groups = a.units / (a.geglu ? 4 : 2);
   int cs = 1;
   while (nrb * cs < 1024 && groups % (cs * 2) == 0 && groups / (cs * 2) >= 3) cs *= 2;
   return cs;
@@ -415,7 +430,7 @@ int mvd_gemm_xs_pick_csplit(const MvdXsArgs& a) {
 int mvd_launch_gemm_xs(const MvdXsArgs& a_in, hipStream_t s) {
   MvdXsArgs a = a_in;
   if (a.csplit <= 0) a.csplit = mvd_gemm_xs_pick_csplit(a);
-  const int groups = a.units / 2;
+  const int groups = a.units / (a.geglu ? 4 : 2);
   if (!mvd_gemm_xs_applicable(a) || groups % a.csplit) {
     mvd_set_error("gemm_xs: M=%d K=%d units=%d geglu=%d csplit=%d is not a shape of the X-stationary kernels", a.M, a.K, a.units, a.geglu, a.csplit);
     return -1;
