@@ -348,6 +348,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
       vo16 = (efr * a.ldo + (efq & 1) * 16 + (efq >> 1) * 8) * 2; vo8 = (efr * a.ldo + efq * 4) * 2;
     } else {
       vo16 = (fr * a.ldo + pair_col) * 2; vo8 = (fr * a.ldo + fq * 4) * 2;
+      // (round 4, timing-only experiment: the same stores aimed at 8 rows x 128 B per instruction instead of 16 rows x 64 B --
+      //  wrong addresses, an upper bound of what a staged whole-line epilogue could buy here: K = 640 dense -4 %, N = 2560 -7 %,
+      //  K >= 1280 and the convolutions -0...2 %; not worth re-laying the tile through LDS: tools/probe_pp_stores.py)
     }
     if constexpr (GEGLU) {
       // column tiles (j, j+1) = (value, gate) of ONE 16-wide output tile; output tiles are then paired for 16-byte stores
