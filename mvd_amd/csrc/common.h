@@ -44,17 +44,21 @@ MVD_DEVINL float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __exp
 //  transcendentals, every operation a v_pk_*_f32 -- half the vector work, |gelu error| <= 5.3e-5 absolute.  Measured: cfg4 cold
 //  63.76 -> 63.53 ms (+0.4 %): the epilogue phase is not bound by its arithmetic alone.  Not worth giving up 1.5e-7; not the default.)
 #ifndef MVD_GELU_POLY
+// (round 4: the 0.5 lives in the coefficients and max(x, 0) is one v_max_f32 by inline asm -- fmaxf costs a canonicalising v_max of its own:
+//  11 VALU + 2 transcendental instructions instead of 16 + 2; the GEGLU kernels are bound by exactly this issue time)
 MVD_DEVINL float gelu_erf_f(float x) {
   const float ax = fabsf(x);
   const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, ax, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
+  float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+  p = fmaf(p, t, 0.5f * 1.421413741f);
+  p = fmaf(p, t, 0.5f * -0.284496736f);
+  p = fmaf(p, t, 0.5f * 0.254829592f);
   const float zl = ax * 0.84932180028801907f;                 // |x| sqrt(log2(e) / 2):  e^{-x^2/2} = 2^{-zl^2}
   const float e = __builtin_amdgcn_exp2f(-zl * zl);
-  const float h = (0.5f * ax) * (p * t) * e;
-  return fmaxf(x, 0.f) - h;
+  const float h = (ax * (p * t)) * e;
+  float mx;                                   // max(x, 0) as ONE instruction (fmaxf / fmed3 come with a canonicalising v_max x, x in front)
+  asm("v_max_f32 %0, 0, %1" : "=v"(mx) : "v"(x));
+  return mx - h;
 }
 #else
 MVD_DEVINL float gelu_erf_f(float x) {
