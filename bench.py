@@ -183,7 +183,7 @@ def _strip_comments(src: str) -> str:
 
 
 def kernel_source_sha(read=None) -> str:
-    """Hash of the HIP sources + headers the library is built from, comments and blank lines excluded: PMC summaries under
+    """Hash of the HIP sources + headers the library is built from (comments and blank lines excluded) and of the hipcc flags: PMC summaries under
     profiles/ are stamped with it, and ``roofline.traffic`` is only quoted from a summary taken on THIS code state.
     ``read(path) -> str`` lets a tool hash another revision of the same files."""
     import hashlib
@@ -195,6 +195,8 @@ def kernel_source_sha(read=None) -> str:
             text = read(path) if read else open(path, "r").read()
             h.update(f.encode())
             h.update(_strip_comments(text).encode())
+    from mvd_amd import _build
+    h.update(" ".join(_build.FLAGS).encode())          # a change of code-generation flags is a change of kernels
     return h.hexdigest()[:16]
 
 

@@ -11,7 +11,14 @@ SOURCES = ["gemm.hip", "gemm_pp.hip", "gemm_sm.hip", "gemm_xs.hip", "attention.h
 # measurement-only experiment kernels: linked by tools/build_variant.py into probe builds (-DMVD_PROBE), never into the product
 PROBE_SOURCES = ["probe/gemm_ring.hip"]     # (+ probe/attention_probe*.inc, included by attention.hip under -DMVD_PROBE)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# -packed-fp32-ops (device code generation without v_pk_{fma,mul,add}_f32): round 4 traced the run-to-run differences of the
+# reverted four-pixel conv_out on a GPU shared by two processes to hipcc's SLP-vectorised `v_pk_fma_f32 ... op_sel:[0,1,0]`
+# (low result half taking the HIGH register of a source pair); the same source with scalar v_fma_f32, or with exactly those 38
+# instructions rewritten in the assembly, is stable (profiles/r04_probe_conv_out4_diagnosis.log).  The product's
+# kernels held ~350 instructions of that class, so packed fp32 selection is off for the whole library: same IEEE operations per
+# element (outputs bit-identical), 0-0.3 % of a step.  The host pass prints "not a recognized feature" for it and ignores it.
+NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", *NO_PACKED_FP32]
 
 
 def _stale(out, deps):

@@ -131,13 +131,28 @@ def test_hand_pipelined_gemms_use_no_scratch_memory(name):
     src = os.path.join(ROOT, "mvd_amd", "csrc", name + ".hip")
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, name + ".s")
-        r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", src, "-o", out],
-                           capture_output=True, text=True, timeout=600)
+        from mvd_amd import _build as B        # the product's own code-generation flags (packed fp32 selection off)
+        r = subprocess.run([B.HIPCC, *B.FLAGS, "--cuda-device-only", "-S", src, "-o", out], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         asm = open(out).read()
     assert "scratch_load" not in asm and "scratch_store" not in asm
     import re
     assert not re.search(r"\.vgpr_spill_count:\s*[1-9]", asm) and not re.search(r"\.private_segment_fixed_size:\s*[1-9]", asm)
+
+
+def test_built_library_holds_no_packed_fp32_arithmetic():
+    """Round 4 traced the four-pixel conv_out's run-to-run differences on a shared GPU to hipcc's SLP-vectorised
+    `v_pk_fma_f32 ... op_sel:[0,1,0]`: the product is built with packed fp32 selection off, and the library that
+    ships (the one build() just produced) is disassembled here to prove no v_pk_{fma,mul,add}_f32 is left in any code object."""
+    import importlib.util
+    from mvd_amd import _build as B
+    lib = B.build()
+    spec = importlib.util.spec_from_file_location("lint_device_isa", os.path.join(ROOT, "tools", "lint_device_isa.py"))
+    lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lint)
+    res = lint.count_packed_fp32(lib)
+    assert res["code_objects"] == len(B.SOURCES) and res["instructions"] > 100000
+    assert res["packed_fp32"] == 0, res
 
 
 def test_block_weight_layout_is_the_lds_image():

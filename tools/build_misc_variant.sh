@@ -1,5 +1,7 @@
 #!/bin/bash
 # Probe library that differs from the product library in misc.hip only:  tools/build_misc_variant.sh <tag> [flags]
+# NOTE: misc.hip is compiled here WITH packed fp32 selection (the product build turns it off, mvd_amd/_build.py NO_PACKED_FP32):
+# that is what reproduces the four-pixel conv_out's run-to-run differences; add the product's flags to get the stable build.
 set -e
 cd "$(dirname "$0")/.."
 tag=$1; shift
