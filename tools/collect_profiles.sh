@@ -6,7 +6,8 @@
 # GRBM_GUI_ACTIVE pass (shader clock under load, tools/clock_summary.py) and the SQ-counter passes on isolated launches.
 set -e -o pipefail
 TAG=${1:-r04}
-STAGE=${2:-ABC}          # A: PMC traffic + the headline line + rocprof stats + sustained + peaked; B: batch 1, 768^2, e2e; C: SQ counters
+STAGE=${2:-ABCD}         # A: PMC traffic + the headline line + rocprof stats + sustained + peaked; B: batch 1, 768^2, e2e; C: SQ counters;
+                         # D: shared-GPU determinism (operator forms beside a second process; the two-rank rehearsal of bench.py)
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -74,6 +75,19 @@ for CS in "FETCH_SIZE" "WRITE_SIZE" "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_
 done
 python tools/pmc_ops_summary.py $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_sq3 $OUT/pmc_sq4 $OUT/pmc_sq5 > $OUT/pmc_sq_counters.txt || true
 rm -rf $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_sq3 $OUT/pmc_sq4 $OUT/pmc_sq5
+fi
+if [[ $STAGE == *D* ]]; then
+# every B = 32 operator form, 30 launches each, while a second process runs the 32-pair forward on the same GPU
+python bench.py --steps 4000 --no-check --no-cpu-baseline --no-profile > /dev/null 2> /dev/null &
+BG=$!
+sleep 60
+REPS=30 timeout -k 10 500 python tools/probe_determinism_shared.py 2>&1 | grep -v amdgpu.ids > $OUT/determinism_shared_gpu.log || echo "determinism probe failed" >> $OUT/determinism_shared_gpu.log
+kill $BG 2> /dev/null || true
+wait $BG 2> /dev/null || true
+grep -c "^ok" $OUT/determinism_shared_gpu.log; grep "^FAIL" $OUT/determinism_shared_gpu.log || echo "no operator form differed"
+# the whole bench.py control flow with two ranks on this ONE GPU (its determinism screen runs on both ranks)
+MVD_BENCH_REHEARSAL=1 python bench.py --gpus 2 --steps 4 --warmup 2 --no-cpu-baseline --no-profile > $OUT/rehearsal_2rank_one_gpu.json 2> $OUT/rehearsal_2rank_one_gpu.err
+python -c "import json;d=json.load(open('$OUT/rehearsal_2rank_one_gpu.json'));print('rehearsal', d['value'], d['output_check'], 'distinct_gpus', d['distinct_gpus'])"
 fi
 # the raw counter csvs are large: keep the summaries only
 ls -la $OUT
