@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmvd_hip.so")
-SOURCES = ["gemm.hip", "gemm_pp.hip", "gemm_sm.hip", "gemm_xs.hip", "attention.hip", "norm.hip", "misc.hip", "sched.hip", "engine.hip", "vae.hip"]
+SOURCES = ["gemm.hip", "gemm_pp.hip", "gemm_sm.hip", "gemm_xs.hip", "conv_ws.hip", "attention.hip", "norm.hip", "misc.hip", "sched.hip", "engine.hip", "vae.hip"]
 # measurement-only experiment kernels: linked by tools/build_variant.py into probe builds (-DMVD_PROBE), never into the product
 PROBE_SOURCES = ["probe/gemm_ring.hip"]     # (+ probe/attention_probe*.inc, included by attention.hip under -DMVD_PROBE)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

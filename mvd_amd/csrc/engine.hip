@@ -329,8 +329,35 @@ struct Ctx {
     return gemm(g);
   }
 
+  // Weight-streaming form (conv_ws.hip) of a stride-1 resnet convolution on one image's 8- or 16-wide map, taken when the packed
+  // twin `<slot>.ws` (packing.pack_ws) is registered: batch 1 at the 8x8 / 16x16 levels is a pure weight stream, which the
+  // implicit-GEMM kernels cut along K with a rendezvous between workgroups (21-63 us against 15-48 us, profiles/r04_probe_conv_ws.log).
+  // A long fused shortcut (> 640 channels) stays with them: its one-tap rounds move four activation bytes per weight byte here.
+  // Returns 1 when it launched, 0 when the caller should go on, < 0 on error.
+  int try_ws(const Act& x, const std::string& slot, const float* bias, const float* rowvec, int ld_rowvec, const bf16_t* res,
+             const bf16_t* sc0, const bf16_t* sc1, int scc0, int scc1, Act& out) {
+    if (err) return err;
+    if (dry || (g_debug_flags & 256) || slot.empty() || !has(slot) || scc0 + scc1 > 640) return 0;
+    MvdWsArgs a; memset(&a, 0, sizeof(a));
+    a.x = x.p; a.B = x.B; a.H = x.H; a.W = x.W; a.C = x.C; a.sc0 = sc0; a.sc1 = sc1; a.scc0 = scc0; a.scc1 = scc1;
+    a.bias = bias; a.rowvec = rowvec; a.ld_rowvec = ld_rowvec; a.res = res; a.ldres = out.C; a.out = out.p; a.ldo = out.C;
+    a.M = out.rows(); a.N = out.C;
+    if (out.H != x.H || out.W != x.W || out.B != x.B || a.M > 256) return 0;      // (beyond one 16x16 map the tiled kernels have the FLOPs to win)
+    a.w = reinterpret_cast<const bf16_t*>(&a);                                     // (placeholder for the shape test)
+    if (!mvd_conv_ws_applicable(a)) return 0;
+    a.w = WB(slot, (int64_t)mvd_conv_ws_packed_elems(x.C, scc0 + scc1, out.C));
+    if (!a.w) return err;
+    e->prof_M = a.M; e->prof_N = a.N; e->prof_K = 9 * x.C + scc0 + scc1; e->prof_tag = 100 + (scc0 ? 1 : 0);
+    const int r = profiled(34, 2.0 * a.M * (double)a.N * (9.0 * x.C + scc0 + scc1), 0.0, [&] { return mvd_launch_conv_ws(a, s); });
+    return r ? r : 1;
+  }
+
   int conv3(const Act& x, int stride, int ups, const bf16_t* w, const float* bias, const float* rowvec, int ld_rowvec,
-            const bf16_t* res, const bf16_t* sc0, const bf16_t* sc1, int scc0, int scc1, Act& out) {
+            const bf16_t* res, const bf16_t* sc0, const bf16_t* sc1, int scc0, int scc1, Act& out, const std::string& ws = std::string()) {
+    if (!ws.empty() && stride == 1 && !ups) {
+      const int r = try_ws(x, ws, bias, rowvec, ld_rowvec, res, sc0, sc1, scc0, scc1, out);
+      if (r) return r < 0 ? r : 0;
+    }
     MvdGemmArgs g; memset(&g, 0, sizeof(g));
     g.seg[0].p0 = x.p; g.seg[0].c0 = x.C; g.seg[0].mode = MVD_A_CONV3; g.seg[0].ksize = 9 * x.C;
     g.seg[0].inH = x.H; g.seg[0].inW = x.W; g.seg[0].stride = stride; g.seg[0].ups = ups;
@@ -454,15 +481,15 @@ struct UNetPass {
     Act h1 = c.new_act(B_, x0.H, x0.W, cout, false);
     const int toff = c.e->temb_off[resnet_idx++];
     CHECK(c.conv3(t1, 1, 0, c.WB(key + ".conv1.w", (int64_t)cout * 9 * cin), c.WF(key + ".conv1.b", cout), tproj + toff, c.e->temb_total,
-                  nullptr, nullptr, nullptr, 0, 0, h1));
+                  nullptr, nullptr, nullptr, 0, 0, h1, key + ".conv1.ws"));
     Act t2 = c.new_act(B_, x0.H, x0.W, cout, false);
     CHECK(c.groupnorm(h1.p, nullptr, cout, 0, B_, hw, cfg.norm_eps, c.WF(key + ".norm2.g", cout), c.WF(key + ".norm2.b", cout), 1, t2.p));
     if (cin != cout) {
       CHECK(c.conv3(t2, 1, 0, c.WB(key + ".conv2.w", (int64_t)cout * (9 * cout + cin)), c.WF(key + ".conv2.b", cout), nullptr, 0, nullptr,
-                    x0.p, x1 ? x1->p : nullptr, cin0, cin1, out));
+                    x0.p, x1 ? x1->p : nullptr, cin0, cin1, out, key + ".conv2.ws"));
     } else {
       CHECK(c.conv3(t2, 1, 0, c.WB(key + ".conv2.w", (int64_t)cout * 9 * cout), c.WF(key + ".conv2.b", cout), nullptr, 0, x0.p, nullptr,
-                    nullptr, 0, 0, out));
+                    nullptr, 0, 0, out, key + ".conv2.ws"));
     }
     c.e->tmp.off = mark;
     return c.err;

@@ -94,6 +94,22 @@ struct MvdXsArgs {
 bool mvd_gemm_xs_applicable(const MvdXsArgs& a);
 int mvd_gemm_xs_pick_csplit(const MvdXsArgs& a);
 int mvd_launch_gemm_xs(const MvdXsArgs& a, hipStream_t s);
+// ---------------------------------------------------------------- weight-streaming 3x3 convolution of small maps (conv_ws.hip)
+// out[M][N] = conv3x3(x; stride 1, pad 1) (+ dense shortcut rows sc0 | sc1) + bias + rowvec[image] + res, one image's 8-wide or
+// 16-wide map per 64-row block; weights host-packed by packing.pack_ws ([N / 16][round][wave][tap][64][8] bf16).
+struct MvdWsArgs {
+  const bf16_t* x; int B, H, W, C;            // NHWC bf16 input
+  const bf16_t* sc0; const bf16_t* sc1; int scc0, scc1;   // dense segment [M][scc0] | [M][scc1] (conv_shortcut fused along K) or null
+  const bf16_t* w;                            // packed weights (mvd_conv_ws_packed_elems elements)
+  const float* bias;                          // [N]
+  const float* rowvec; int ld_rowvec;         // per-image row vector [B][ld_rowvec] (time embedding) or null
+  const bf16_t* res; int ldres;               // residual [M][ldres] or null
+  bf16_t* out; int ldo;
+  int M, N;                                   // M = B * H * W
+};
+bool mvd_conv_ws_applicable(const MvdWsArgs& a);
+size_t mvd_conv_ws_packed_elems(int C, int sc, int N);
+int mvd_launch_conv_ws(const MvdWsArgs& a, hipStream_t s);
 #define MVD_OP_SPLITK_COUNTERS 4096   // tile counters behind the partials of an mvd_op_linear / mvd_op_conv3x3 split-K workspace
 // sum the split-K partials and apply the GEMM epilogue (bias, row vector, alpha, residual) -> out
 int mvd_launch_splitk_reduce(const MvdGemmArgs& a, hipStream_t s);

@@ -288,7 +288,9 @@ class MVDEngine:
                        20: "gemm_sm_64x64", 21: "gemm_sm_128x64", 22: "gemm_sm_64x128", 23: "gemm_sm_128x128", 24: "gemm_sm_64x160",
                        25: "gemm_sm_128x160", 26: "gemm_sm_64x320",
                        # X-stationary short-K kernels (gemm_xs.hip)
-                       30: "gemm_xs_dense", 31: "gemm_xs_residual", 32: "gemm_xs_ln_dense", 33: "gemm_xs_geglu"}
+                       30: "gemm_xs_dense", 31: "gemm_xs_residual", 32: "gemm_xs_ln_dense", 33: "gemm_xs_geglu",
+                       # weight-streaming convolution of one image's 8x8 / 16x16 map (conv_ws.hip)
+                       34: "conv_ws"}
 
     def set_profiling(self, enable):
         """False / 0: off.  True / 1: per-launch HIP events on ONE stream (serial kernel times).  2: per-launch events with the

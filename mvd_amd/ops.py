@@ -75,6 +75,22 @@ def linear_xs(x, w_packed, geglu=False, ln=False, eps=1e-5, res=None, csplit=0, 
     return out
 
 
+def conv3x3_ws(x, w_packed, bias, n, rowvec=None, res=None, shortcut=None, shortcut2=None):
+    """The weight-streaming 3x3 convolution of small maps (conv_ws.hip): x (B, H, W, C) bf16 with W in {8, 16}, H * W % 64 == 0,
+    B * H * W <= 512, C % 128 == 0; ``w_packed`` from packing.pack_ws (conv weight [n][C][3][3] and, optionally, the 1x1
+    shortcut weight over ``shortcut`` | ``shortcut2`` rows); stride 1, padding 1.  Returns (B, H, W, n) bf16."""
+    _bf16(x, w_packed, res, shortcut, shortcut2)
+    b, h, w, c = x.shape
+    out = torch.empty(b, h, w, n, device=x.device, dtype=torch.bfloat16)
+    assert bias.dtype == torch.float32 and bias.numel() == n and x.is_contiguous()
+    assert rowvec is None or (rowvec.dtype == torch.float32 and rowvec.stride(1) == 1)
+    pp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
+    L.call("mvd_op_conv3x3_ws", _p(x), b, h, w, c, _p(w_packed), _p(bias), pp(rowvec), rowvec.stride(0) if rowvec is not None else 0,
+           pp(res), pp(shortcut), pp(shortcut2), shortcut.shape[-1] if shortcut is not None else 0,
+           shortcut2.shape[-1] if shortcut2 is not None else 0, _p(out), n, _s())
+    return out
+
+
 def conv3x3(x, w_packed, bias=None, stride=1, upsample=False, rowvec=None, res=None, shortcut=None,
             shortcut2=None, force_cfg=-1, splitk=1, asym_pad=False):
     """x: (B,H,W,Cin) bf16; w_packed: (Cout, 9*Cin [+ Csc]) bf16 tap-major.  asym_pad (stride 2): zero padding on the

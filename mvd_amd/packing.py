@@ -112,6 +112,30 @@ def pack_xs(w: torch.Tensor, bias, geglu: bool = False, device=None) -> torch.Te
     return out.reshape(units, ks + 1, 64, 8).contiguous()
 
 
+WS_MAX_SHORTCUT = 640      # (engine.hip try_ws: longer fused shortcuts are not taken)
+
+
+def pack_ws(w4: torch.Tensor, wsc=None, device=None) -> torch.Tensor:
+    """conv weight ``[N][C][3][3]`` (+ 1x1 shortcut weight ``[N][Csc]`` or None) -> the weight stream of conv_ws.hip:
+    per 16-channel column tile, the convolution's rounds ``[C/128][wave 4][tap 9][lane 64][8]`` then the shortcut's rounds
+    ``[Csc/128][wave 4][lane 64][8]`` (bf16).  Lane ``(i, h) = (lane & 15, lane >> 4)`` of a 1 KB block holds the MFMA A-operand
+    fragment ``W[16 ct + i][128 rd + 32 wave + 8 h .. + 8]`` of tap ``3 ky + kx`` (input pixel (y + ky - 1, x + kx - 1))."""
+    device = device if device is not None else w4.device
+    w4 = w4.detach().to(device=device, dtype=torch.float32)
+    n, c = w4.shape[0], w4.shape[1]
+    assert n % 16 == 0 and c % 128 == 0 and tuple(w4.shape[2:]) == (3, 3), tuple(w4.shape)
+    t = w4.permute(0, 2, 3, 1).reshape(n // 16, 16, 9, c // 128, 4, 4, 8)        # [ct][i][tap][rd][wave][h][8]
+    conv = t.permute(0, 3, 4, 2, 5, 1, 6).reshape(n // 16, -1)                   # [ct][rd][wave][tap][h][i][8]
+    parts = [conv]
+    if wsc is not None:
+        wsc = wsc.detach().to(device=device, dtype=torch.float32).reshape(n, -1)
+        sc = wsc.shape[1]
+        assert sc % 128 == 0, sc
+        u = wsc.reshape(n // 16, 16, sc // 128, 4, 4, 8)                         # [ct][i][rd][wave][h][8]
+        parts.append(u.permute(0, 2, 3, 4, 1, 5).reshape(n // 16, -1))           # [ct][rd][wave][h][i][8]
+    return torch.cat(parts, 1).to(torch.bfloat16).contiguous().reshape(-1)
+
+
 # LayerNorm fold: only the 64x64 / 32x32 levels (C = 320 / 640 in SD-2.1) ever reach the fused kernel (it needs >= 200
 # tiles of 256x320, i.e. many rows); deeper levels keep ln_kernel + the plain GEMM and get no folded twin
 LN_FOLD_MAX_C = 1 << 30     # every level: the small-M kernels (batch 1) fold at C = 1280 too (the M = 32-images kernels stop at 640)
@@ -154,6 +178,15 @@ def pack_unet(sd: Dict[str, torch.Tensor], cfg: UNetConfig, device, adapter: boo
             b2 = b2 + sd[f"{key}.conv_shortcut.bias"].detach().float()
         out[f"{key}.conv2.w"] = _bf(w2, device)
         out[f"{key}.conv2.b"] = _f32(b2, device)
+        # weight-streaming twins (conv_ws.hip) for the widest level(s) -- the 16x16 and 8x8 maps of a 64x64 latent, where a
+        # batch-1 launch is a pure weight stream.  A fused shortcut longer than 640 channels stays with the tiled kernels.
+        if cout == max(cfg.block_out_channels) and cout % 16 == 0 and cout % 128 == 0:
+            if cin % 128 == 0:
+                out[f"{key}.conv1.ws"] = pack_ws(sd[f"{key}.conv1.weight"], None, device)
+            if cin == cout:
+                out[f"{key}.conv2.ws"] = pack_ws(sd[f"{key}.conv2.weight"], None, device)
+            elif cin % 128 == 0 and cin <= WS_MAX_SHORTCUT:
+                out[f"{key}.conv2.ws"] = pack_ws(sd[f"{key}.conv2.weight"], sd[f"{key}.conv_shortcut.weight"].reshape(cout, cin), device)
         tw.append(sd[f"{key}.time_emb_proj.weight"].detach().float())
         tb.append(sd[f"{key}.time_emb_proj.bias"].detach().float())
     out["temb_proj.w"] = _bf(torch.cat(tw, 0), device)

@@ -1,0 +1,54 @@
+"""packing.pack_ws: the fragment-ordered weight stream of the weight-streaming convolution (mvd_amd/csrc/conv_ws.hip).  The
+layout is checked element by element against its definition -- [column tile][round][wave][tap][lane][8] for the convolution,
+then [round][wave][lane][8] for the fused 1x1 shortcut, lane (i, h) = (lane & 15, lane >> 4) holding W[16 ct + i][128 rd + 32 wave
++ 8 h + j] of tap 3 ky + kx -- and pack_unet registers the twins exactly where the engine looks for them."""
+import torch
+
+from mvd_amd.packing import WS_MAX_SHORTCUT, pack_ws
+
+
+def test_pack_ws_layout_by_definition():
+    g = torch.Generator().manual_seed(0)
+    n, c, sc = 48, 256, 384
+    w4 = torch.randn(n, c, 3, 3, generator=g).to(torch.bfloat16)
+    wsc = torch.randn(n, sc, generator=g).to(torch.bfloat16)
+    p = pack_ws(w4, wsc)
+    rc, rs = c // 128, sc // 128
+    tile = (rc * 9 + rs) * 4 * 512
+    assert p.dtype == torch.bfloat16 and p.numel() == (n // 16) * tile == n * (9 * c + sc)
+    p = p.reshape(n // 16, tile)
+    for ct in range(n // 16):
+        conv = p[ct, :rc * 4 * 9 * 512].reshape(rc, 4, 9, 64, 8)
+        short = p[ct, rc * 4 * 9 * 512:].reshape(rs, 4, 64, 8)
+        for lane in (0, 7, 15, 16, 33, 63):
+            i, h = lane & 15, lane >> 4
+            for rd in range(rc):
+                for wave in range(4):
+                    k0 = 128 * rd + 32 * wave + 8 * h
+                    for tap in range(9):
+                        assert torch.equal(conv[rd, wave, tap, lane], w4[16 * ct + i, k0:k0 + 8, tap // 3, tap % 3])
+            for rd in range(rs):
+                for wave in range(4):
+                    k0 = 128 * rd + 32 * wave + 8 * h
+                    assert torch.equal(short[rd, wave, lane], wsc[16 * ct + i, k0:k0 + 8])
+
+
+def test_pack_unet_registers_ws_twins_for_the_widest_level_only():
+    from mvd_amd.config import UNetConfig
+    from mvd_amd.packing import pack_unet
+    from oracle import sd21_unet as OU                     # (test infrastructure: seeded weights of the tiny topology)
+    cfg = UNetConfig.tiny()
+    sd = OU.init_params(OU.UNetConfig.tiny(), seed=3)
+    packed = pack_unet(sd, cfg, "cpu", adapter=False)
+    top = max(cfg.block_out_channels)
+    seen = 0
+    for key, cin, cout in cfg.resnets():
+        has1, has2 = f"{key}.conv1.ws" in packed, f"{key}.conv2.ws" in packed
+        assert has1 == (cout == top and cin % 128 == 0), key
+        assert has2 == (cout == top and (cin == cout or (cin % 128 == 0 and cin <= WS_MAX_SHORTCUT))), key
+        if has1:
+            assert packed[f"{key}.conv1.ws"].numel() == cout * 9 * cin
+        if has2:
+            assert packed[f"{key}.conv2.ws"].numel() == cout * (9 * cout + (cin if cin != cout else 0))
+        seen += has1 + has2
+    assert seen > 0

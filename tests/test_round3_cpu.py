@@ -121,7 +121,7 @@ def test_vae_snapshot_that_fails_to_load_is_an_error_not_a_missing_vae(tmp_path)
         _optional_components(str(tmp_path / "snap"), torch.float32)
 
 
-@pytest.mark.parametrize("name", ["gemm_sm", "gemm_pp", "gemm_xs", "attention"])
+@pytest.mark.parametrize("name", ["gemm_sm", "gemm_pp", "gemm_xs", "conv_ws", "attention"])
 def test_hand_pipelined_gemms_use_no_scratch_memory(name):
     """hipcc turns a runtime-indexed register array -- or one live value too many in a 256-register kernel -- into scratch_load /
     scratch_store, which also count on vmcnt beside the hand-counted LDS-DMA waits: the small-M GEMM, the ping-pong GEMM, the X-stationary GEMM

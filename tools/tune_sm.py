@@ -17,6 +17,8 @@ ap.add_argument("--quick", action="store_true")
 ap.add_argument("--filter", default="")
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--adapter", action="store_true", help="cfg3 shapes (adapter rows / columns) instead of the base UNet's")
+ap.add_argument("--warm-weights", action="store_true", help="re-read the WEIGHT operand too just before the launch (what a prefetcher running ahead of the launch chain would give)")
+ap.add_argument("--auto-only", action="store_true", help="time the heuristic's launch only, no sweep")
 args = ap.parse_args()
 B = int(os.environ.get("TUNE_B", "1"))
 SM_TILES = {0: (64, 64), 1: (128, 64), 2: (64, 128), 3: (128, 128), 4: (64, 160), 5: (128, 160), 6: (64, 320)}
@@ -124,7 +126,7 @@ def make(kind, p):
             L.call("mvd_op_linear", C.c_void_p(a.data_ptr()), None, K, 0, C.c_void_p(w.data_ptr()), C.c_void_p(bias.data_ptr()), None, 0, 0,
                    C.c_void_p(res.data_ptr()) if res is not None else None, 1.0, int(p["geglu"]), C.c_void_p(out.data_ptr()), int(f32), M, N,
                    cfg, sk, C.c_void_p(ws.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
-        return run, [a] + ([res] if res is not None else []), 2.0 * M * N * K, N, K, M
+        return run, [a] + ([res] if res is not None else []) + ([w] if args.warm_weights else []), 2.0 * M * N * K, N, K, M
     hw, cin, cout, sc = p["hw"], p["cin"], p["cout"], p["sc"]
     oh = hw * 2 if p["ups"] else (hw // 2 if p["stride"] == 2 else hw)
     M, K = B * oh * oh, 9 * cin + sc
@@ -141,7 +143,7 @@ def make(kind, p):
     def run(cfg, sk):
         L.call("mvd_op_conv3x3", ptr(x), B, hw, hw, cin, p["stride"], p["ups"], 0, ptr(w), ptr(bias), ptr(rowvec), cout if rowvec is not None else 0,
                ptr(res), ptr(scx), None, sc, 0, ptr(out), cout, cfg, sk, ptr(ws), C.c_void_p(torch.cuda.current_stream().cuda_stream))
-    return run, [x] + [t for t in (res, scx) if t is not None], 2.0 * M * cout * K, cout, K, M
+    return run, [x] + [t for t in (res, scx) if t is not None] + ([w] if args.warm_weights else []), 2.0 * M * cout * K, cout, K, M
 
 
 print(f"# B={B} adapter={args.adapter} empty bracket {EMPTY:.2f} us (subtracted); times in us, median of {args.iters}", flush=True)
@@ -156,6 +158,8 @@ for kind, name, p, count in unet_shapes(args.adapter):
     res = []
     nkt = K // 64
     for tile, (bm, bn) in SM_TILES.items():
+        if args.auto_only:
+            break
         if N % bn or (geglu and (bn // 32) % 2):
             continue
         tiles = ((M + bm - 1) // bm) * (N // bn)
