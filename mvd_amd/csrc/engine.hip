@@ -161,6 +161,73 @@ namespace {
 
 #define CHECK(x) do { int _r = (x); if (_r) return _r; } while (0)
 
+#ifdef MVD_PROBE
+struct WsCheckRec { std::string slot; int set; bool side; const char* p[4]; size_t n[4]; };
+static std::vector<WsCheckRec> g_ws_recs;
+static unsigned long long* g_ws_cnt = nullptr;      // pinned: [launch][2] = {elements beyond tolerance, elements compared}
+__global__ void ws_check_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, long n, unsigned long long* cnt_l, unsigned long long* cnt, unsigned long long launch) {
+  unsigned long long bad = 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float va = bflo((unsigned)a[i]), vb = bflo((unsigned)b[i]);
+    if (!(fabsf(va - vb) <= 0.03f * fabsf(vb) + 0.05f)) {
+      ++bad;
+      const unsigned long long k = __hip_atomic_fetch_add(cnt + 8192 * 2 - 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (k < 4096) { cnt[8192 * 2 + 2 * k] = (unsigned long long)i | (launch << 40); cnt[8192 * 2 + 2 * k + 1] = ((unsigned long long)__float_as_uint(va) << 32) | __float_as_uint(vb); }
+    }
+  }
+  if (bad) __hip_atomic_fetch_add(cnt_l, bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(cnt_l + 1, (unsigned long long)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+extern "C" void mvd_debug_ws_check_report(void);
+static const char* g_ws_ptrs[4]; static size_t g_ws_lens[4];
+static void ws_check_launch(const std::string& slot, int set, bool side, const bf16_t* a, const bf16_t* b, long n, hipStream_t s) {
+  if (!g_ws_cnt) {
+    (void)hipHostMalloc(&g_ws_cnt, (8192 * 2 + 8192) * sizeof(unsigned long long), hipHostMallocMapped); memset(g_ws_cnt, 0, (8192 * 2 + 8192) * sizeof(unsigned long long));
+    atexit(mvd_debug_ws_check_report);
+  }
+  if (g_ws_recs.size() >= 4096) return;
+  g_ws_recs.push_back({slot, set, side, {g_ws_ptrs[0], g_ws_ptrs[1], g_ws_ptrs[2], g_ws_ptrs[3]}, {g_ws_lens[0], g_ws_lens[1], g_ws_lens[2], g_ws_lens[3]}});
+  hipLaunchKernelGGL(ws_check_kernel, dim3(64), dim3(256), 0, s, a, b, n, g_ws_cnt + 2 * (g_ws_recs.size() - 1), g_ws_cnt, (unsigned long long)(g_ws_recs.size() - 1));
+}
+extern "C" void mvd_debug_ws_check_report(void) {
+  (void)hipDeviceSynchronize();
+  int nbad = 0;
+  for (size_t i = 0; i < g_ws_recs.size(); ++i)
+    if (g_ws_cnt[2 * i]) { ++nbad; fprintf(stderr, "ws check: launch %zu %s (set %d, %s stream): %llu of %llu elements beyond tolerance\n", i, g_ws_recs[i].slot.c_str(), g_ws_recs[i].set, g_ws_recs[i].side ? "side" : "main", g_ws_cnt[2 * i], g_ws_cnt[2 * i + 1]); }
+  {   // where the mismatches sit: (launch, row m, channel n) histogram by row block of 64 and channel tile of 16
+    const unsigned long long nlog = g_ws_cnt[8192 * 2 - 1] < 4096 ? g_ws_cnt[8192 * 2 - 1] : 4096;
+    std::unordered_map<unsigned long long, int> tiles;
+    for (unsigned long long k = 0; k < nlog; ++k) {
+      const unsigned long long v = g_ws_cnt[8192 * 2 + 2 * k], launch = v >> 40, idx = v & ((1ull << 40) - 1);
+      const int N = 0; (void)N;
+      tiles[(launch << 40) | idx] = 1;
+    }
+    // print the first 24 raw entries (index decoded by the reader: idx = m * N + n)
+    for (unsigned long long k = 0; k < nlog && k < 24; ++k) {
+      const unsigned long long v = g_ws_cnt[8192 * 2 + 2 * k], w = g_ws_cnt[8192 * 2 + 2 * k + 1];
+      const unsigned ua = (unsigned)(w >> 32), ub = (unsigned)w; float fa, fb; memcpy(&fa, &ua, 4); memcpy(&fb, &ub, 4);
+      fprintf(stderr, "ws check: mismatch launch %llu idx %llu: ws %g tiled %g\n", v >> 40, v & ((1ull << 40) - 1), fa, fb);
+    }
+  }
+  // operand ranges (x, sc0, sc1, out) of launches of DIFFERENT passes of one forward must never overlap
+  static const char* kind[4] = {"x", "sc0", "sc1", "out"};
+  int nov = 0;
+  for (size_t i = 0; i < g_ws_recs.size() && nov < 12; ++i)
+    for (size_t j = i + 1; j < g_ws_recs.size() && j < i + 40 && nov < 12; ++j) {
+      if (g_ws_recs[i].side == g_ws_recs[j].side) continue;
+      for (int u = 0; u < 4; ++u) for (int v = 0; v < 4; ++v) {
+        const char* a0 = g_ws_recs[i].p[u]; const char* b0 = g_ws_recs[j].p[v];
+        if (!a0 || !b0 || (u != 3 && v != 3)) continue;               // (an overlap matters when one side writes)
+        if (a0 < b0 + g_ws_recs[j].n[v] && b0 < a0 + g_ws_recs[i].n[u]) {
+          ++nov; fprintf(stderr, "ws check: OVERLAP launch %zu %s (%s stream) %s [%p, +%zu) with launch %zu %s (%s stream) %s [%p, +%zu)\n", i, g_ws_recs[i].slot.c_str(), g_ws_recs[i].side ? "side" : "main", kind[u], (const void*)a0, g_ws_recs[i].n[u], j, g_ws_recs[j].slot.c_str(), g_ws_recs[j].side ? "side" : "main", kind[v], (const void*)b0, g_ws_recs[j].n[v]);
+        }
+      }
+    }
+  fprintf(stderr, "ws check: %d operand overlaps between the two passes\n", nov);
+  fprintf(stderr, "ws check: %zu conv_ws launches compared with the tiled kernel, %d with elements beyond tolerance\n", g_ws_recs.size(), nbad);
+}
+#endif
+
 struct Ctx {
   mvd_engine* e;
   hipStream_t s;
@@ -330,25 +397,56 @@ struct Ctx {
   }
 
   // Weight-streaming form (conv_ws.hip) of a stride-1 resnet convolution on one image's 8- or 16-wide map, taken when the packed
-  // twin `<slot>.ws` (packing.pack_ws) is registered: batch 1 at the 8x8 / 16x16 levels is a pure weight stream, which the
+  // twin `<slot>.ws` (packing.pack_ws) is registered: batch 1 at the 8x8 / 16x16 / 32x32 levels is a weight stream, which the
   // implicit-GEMM kernels cut along K with a rendezvous between workgroups (21-63 us against 15-48 us, profiles/r04_probe_conv_ws.log).
-  // A long fused shortcut (> 640 channels) stays with them: its one-tap rounds move four activation bytes per weight byte here.
   // Returns 1 when it launched, 0 when the caller should go on, < 0 on error.
   int try_ws(const Act& x, const std::string& slot, const float* bias, const float* rowvec, int ld_rowvec, const bf16_t* res,
              const bf16_t* sc0, const bf16_t* sc1, int scc0, int scc1, Act& out) {
     if (err) return err;
-    if (dry || (g_debug_flags & 256) || slot.empty() || !has(slot) || scc0 + scc1 > 640) return 0;
+    if (dry || (g_debug_flags & 256) || slot.empty() || !has(slot)) return 0;
+    // The fused shortcut (conv2 | conv_shortcut) stays with the tiled kernels: in the two-stream forward -- and only there -- about one
+    // workgroup in 10^4 of those launches came out one k-chunk off (the in-situ comparison of probe builds, flag 32768:
+    // profiles/r04_probe_conv_ws_in_situ.log; not reproduced at op level, not cured by draining every round).  Probe builds can
+    // switch it back on for that comparison (flag 65536).
+    if (scc0 && !(g_debug_flags & 65536)) return 0;
     MvdWsArgs a; memset(&a, 0, sizeof(a));
     a.x = x.p; a.B = x.B; a.H = x.H; a.W = x.W; a.C = x.C; a.sc0 = sc0; a.sc1 = sc1; a.scc0 = scc0; a.scc1 = scc1;
     a.bias = bias; a.rowvec = rowvec; a.ld_rowvec = ld_rowvec; a.res = res; a.ldres = out.C; a.out = out.p; a.ldo = out.C;
     a.M = out.rows(); a.N = out.C;
-    if (out.H != x.H || out.W != x.W || out.B != x.B || a.M > 256) return 0;      // (beyond one 16x16 map the tiled kernels have the FLOPs to win)
+    // (debug flags, A/B only: 512 = maps of at most 256 pixels, 1024 = 64-pixel blocks everywhere, 2048 = no fused shortcut)
+    if ((g_debug_flags & 512) && a.M > 256) return 0;
+    if (g_debug_flags & 1024) a.variant = 1;
+    if ((g_debug_flags & 2048) && scc0) return 0;
+    if ((g_debug_flags & 4096) && nowait) return 0;             // (4096: not in the encoder pass of a two-stream forward; 8192: only there)
+    if ((g_debug_flags & 8192) && !nowait) return 0;
+    if (out.H != x.H || out.W != x.W || out.B != x.B || a.M > 1024) return 0;     // (one 32x32 map at most: beyond, the tiled kernels have the FLOPs to win)
     a.w = reinterpret_cast<const bf16_t*>(&a);                                     // (placeholder for the shape test)
     if (!mvd_conv_ws_applicable(a)) return 0;
     a.w = WB(slot, (int64_t)mvd_conv_ws_packed_elems(x.C, scc0 + scc1, out.C));
     if (!a.w) return err;
     e->prof_M = a.M; e->prof_N = a.N; e->prof_K = 9 * x.C + scc0 + scc1; e->prof_tag = 100 + (scc0 ? 1 : 0);
     const int r = profiled(34, 2.0 * a.M * (double)a.N * (9.0 * x.C + scc0 + scc1), 0.0, [&] { return mvd_launch_conv_ws(a, s); });
+    if (!r && (g_debug_flags & 16384)) return 0;              // (16384, A/B only: the tiled kernel runs as well and overwrites the result)
+#ifdef MVD_PROBE
+    // probe builds, flag 32768: the tiled kernel computes the same launch into a scratch tensor and a compare kernel counts the
+    // elements that differ by more than rounding into pinned host memory -- no synchronise; mvd_debug_ws_check_report() prints
+    if (!r && (g_debug_flags & 32768)) {
+      const size_t mark = e->tmp.off;
+      Act chk = new_act(out.B, out.H, out.W, out.C, false);
+      const bf16_t* wold = WB(slot.substr(0, slot.size() - 1), (int64_t)out.C * (9 * x.C + scc0 + scc1));   // "<..>.convN.ws" -> "<..>.convN.w"
+      if (wold) {
+        const int saved = g_debug_flags; g_debug_flags |= 256;
+        conv3(x, 1, 0, wold, bias, rowvec, ld_rowvec, res, sc0, sc1, scc0, scc1, chk);
+        g_debug_flags = saved;
+        g_ws_ptrs[0] = (const char*)x.p; g_ws_lens[0] = (size_t)x.rows() * x.C * 2;
+        g_ws_ptrs[1] = (const char*)sc0; g_ws_lens[1] = (size_t)out.rows() * scc0 * 2;
+        g_ws_ptrs[2] = (const char*)sc1; g_ws_lens[2] = (size_t)out.rows() * scc1 * 2;
+        g_ws_ptrs[3] = (const char*)out.p; g_ws_lens[3] = (size_t)out.rows() * out.C * 2;
+        ws_check_launch(slot, set, nowait, out.p, chk.p, (long)out.rows() * out.C, s);
+      }
+      e->tmp.off = mark;
+    }
+#endif
     return r ? r : 1;
   }
 

@@ -95,8 +95,8 @@ bool mvd_gemm_xs_applicable(const MvdXsArgs& a);
 int mvd_gemm_xs_pick_csplit(const MvdXsArgs& a);
 int mvd_launch_gemm_xs(const MvdXsArgs& a, hipStream_t s);
 // ---------------------------------------------------------------- weight-streaming 3x3 convolution of small maps (conv_ws.hip)
-// out[M][N] = conv3x3(x; stride 1, pad 1) (+ dense shortcut rows sc0 | sc1) + bias + rowvec[image] + res, one image's 8-wide or
-// 16-wide map per 64-row block; weights host-packed by packing.pack_ws ([N / 16][round][wave][tap][64][8] bf16).
+// out[M][N] = conv3x3(x; stride 1, pad 1) (+ dense shortcut rows sc0 | sc1) + bias + rowvec[image] + res, one image's 8-, 16- or
+// 32-wide map per 64- / 128-row block; weights host-packed by packing.pack_ws ([N / 16][round][wave][tap][64][8] bf16).
 struct MvdWsArgs {
   const bf16_t* x; int B, H, W, C;            // NHWC bf16 input
   const bf16_t* sc0; const bf16_t* sc1; int scc0, scc1;   // dense segment [M][scc0] | [M][scc1] (conv_shortcut fused along K) or null
@@ -106,6 +106,7 @@ struct MvdWsArgs {
   const bf16_t* res; int ldres;               // residual [M][ldres] or null
   bf16_t* out; int ldo;
   int M, N;                                   // M = B * H * W
+  int variant;                                // 0: the launcher's choice; 1 / 2: force 64- / 128-pixel blocks (tests, probes; conv_ws.hip)
 };
 bool mvd_conv_ws_applicable(const MvdWsArgs& a);
 size_t mvd_conv_ws_packed_elems(int C, int sc, int N);

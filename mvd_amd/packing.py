@@ -18,6 +18,8 @@ from __future__ import annotations
 
 from typing import Dict
 
+import os
+
 import torch
 
 from .config import UNetConfig
@@ -112,7 +114,9 @@ def pack_xs(w: torch.Tensor, bias, geglu: bool = False, device=None) -> torch.Te
     return out.reshape(units, ks + 1, 64, 8).contiguous()
 
 
-WS_MAX_SHORTCUT = 640      # (engine.hip try_ws: longer fused shortcuts are not taken)
+# conv2 | conv_shortcut twins: the kernel takes them (tests/test_conv_ws_gpu.py) but the engine keeps the tiled kernels for those
+# launches (engine.hip try_ws: run-to-run differences in the two-stream forward), so by default they are not packed
+WS_PACK_SHORTCUT = bool(int(os.environ.get("MVD_WS_PACK_SHORTCUT", "0")))
 
 
 def pack_ws(w4: torch.Tensor, wsc=None, device=None) -> torch.Tensor:
@@ -178,14 +182,14 @@ def pack_unet(sd: Dict[str, torch.Tensor], cfg: UNetConfig, device, adapter: boo
             b2 = b2 + sd[f"{key}.conv_shortcut.bias"].detach().float()
         out[f"{key}.conv2.w"] = _bf(w2, device)
         out[f"{key}.conv2.b"] = _f32(b2, device)
-        # weight-streaming twins (conv_ws.hip) for the widest level(s) -- the 16x16 and 8x8 maps of a 64x64 latent, where a
-        # batch-1 launch is a pure weight stream.  A fused shortcut longer than 640 channels stays with the tiled kernels.
-        if cout == max(cfg.block_out_channels) and cout % 16 == 0 and cout % 128 == 0:
+        # weight-streaming twins (conv_ws.hip) for every level but the first -- the 32x32, 16x16 and 8x8 maps of a 64x64 latent,
+        # where a batch-1 launch is a weight stream (input / output widths the kernel takes: % 128 and % 16)
+        if cout > cfg.block_out_channels[0] and cout % 128 == 0:
             if cin % 128 == 0:
                 out[f"{key}.conv1.ws"] = pack_ws(sd[f"{key}.conv1.weight"], None, device)
             if cin == cout:
                 out[f"{key}.conv2.ws"] = pack_ws(sd[f"{key}.conv2.weight"], None, device)
-            elif cin % 128 == 0 and cin <= WS_MAX_SHORTCUT:
+            elif cin % 128 == 0 and WS_PACK_SHORTCUT:
                 out[f"{key}.conv2.ws"] = pack_ws(sd[f"{key}.conv2.weight"], sd[f"{key}.conv_shortcut.weight"].reshape(cout, cin), device)
         tw.append(sd[f"{key}.time_emb_proj.weight"].detach().float())
         tb.append(sd[f"{key}.time_emb_proj.bias"].detach().float())

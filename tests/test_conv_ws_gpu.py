@@ -1,6 +1,6 @@
 """Weight-streaming 3x3 convolution of small maps (mvd_amd/csrc/conv_ws.hip) vs a PyTorch fp32 conv2d of the same op on
 bf16-rounded inputs.  Tolerance |err| <= 2^-7 * max|ref| as for the other GEMM / conv kernels (tests/test_ops_gpu.py): the
-output is bf16, accumulation fp32 in a different order than the reference's.  Covers both map widths (8, 16), several images
+output is bf16, accumulation fp32 in a different order than the reference's.  Covers the three map widths (8, 16, 32) and both block heights, several images
 per launch, the fused dense shortcut with one and two sources, the time-embedding row vector, the residual, the map borders
 (a one-hot input makes every tap land on a known pixel) and agreement with the implicit-GEMM kernel the engine used before."""
 import math
@@ -45,21 +45,28 @@ def reference(x, w4, bias, wsc=None, sc=None, rowvec=None, res=None):
     return y
 
 
+def variants(h, w):
+    """kernel forms that take an h x w map: 0 = the launcher's choice, 1 = 64-pixel blocks, 2 = 128-pixel blocks (16-wide maps)"""
+    return [0, 1] + ([2] if w == 16 and (h * w) % 128 == 0 else [])
+
+
 @pytest.mark.parametrize("b,h,w,c,n", [(1, 8, 8, 1280, 1280), (1, 16, 16, 640, 1280), (2, 8, 8, 256, 64), (1, 16, 16, 128, 48),
-                                       (3, 8, 8, 128, 16), (1, 8, 16, 256, 32), (2, 16, 16, 128, 160)])
+                                       (3, 8, 8, 128, 16), (1, 8, 16, 256, 32), (2, 16, 16, 128, 160), (1, 32, 32, 640, 640),
+                                       (1, 4, 32, 128, 16), (1, 24, 16, 128, 32)])
 def test_conv_ws_plain_rowvec_residual(ops, b, h, w, c, n):
     from mvd_amd.packing import pack_ws
     x, w4 = rnd(b, h, w, c, seed=1), rnd(n, c, 3, 3, scale=1 / math.sqrt(9 * c), seed=2)
     bias, rowvec, res = rnd(n, seed=3, dtype=torch.float32), rnd(b, n, seed=4, dtype=torch.float32), rnd(b, h, w, n, seed=5)
     wp = pack_ws(w4).cuda()
     assert wp.numel() == n * 9 * c
-    close(ops.conv3x3_ws(x.cuda(), wp, bias.cuda(), n), reference(x, w4, bias), what="ws plain")
-    close(ops.conv3x3_ws(x.cuda(), wp, bias.cuda(), n, rowvec=rowvec.cuda(), res=res.cuda()),
-          reference(x, w4, bias, rowvec=rowvec, res=res), what="ws rowvec + residual")
+    for v in variants(h, w):
+        close(ops.conv3x3_ws(x.cuda(), wp, bias.cuda(), n, variant=v), reference(x, w4, bias), what=f"ws plain, variant {v}")
+        close(ops.conv3x3_ws(x.cuda(), wp, bias.cuda(), n, rowvec=rowvec.cuda(), res=res.cuda(), variant=v),
+              reference(x, w4, bias, rowvec=rowvec, res=res), what=f"ws rowvec + residual, variant {v}")
 
 
 @pytest.mark.parametrize("b,h,w,c,n,s0,s1", [(1, 8, 8, 1280, 1280, 1280, 1280), (1, 16, 16, 1280, 1280, 640, 0), (2, 8, 8, 128, 64, 128, 256),
-                                             (1, 16, 16, 256, 32, 384, 0)])
+                                             (1, 16, 16, 256, 32, 384, 0), (1, 32, 32, 128, 32, 256, 128)])
 def test_conv_ws_fused_shortcut(ops, b, h, w, c, n, s0, s1):
     """conv2 | conv_shortcut of a channel-changing resnet: the 1x1 shortcut over the block input (one tensor, or the two halves
     of a skip concatenation) is a second K segment of the same launch."""
@@ -71,11 +78,12 @@ def test_conv_ws_fused_shortcut(ops, b, h, w, c, n, s0, s1):
     bias = rnd(n, seed=3, dtype=torch.float32)
     wp = pack_ws(w4, wsc).cuda()
     sc = torch.cat([sc0, sc1], -1) if s1 else sc0
-    got = ops.conv3x3_ws(x.cuda(), wp, bias.cuda(), n, shortcut=sc0.cuda(), shortcut2=sc1.cuda() if s1 else None)
-    close(got, reference(x, w4, bias, wsc=wsc, sc=sc), what="ws + shortcut")
+    for v in variants(h, w):
+        got = ops.conv3x3_ws(x.cuda(), wp, bias.cuda(), n, shortcut=sc0.cuda(), shortcut2=sc1.cuda() if s1 else None, variant=v)
+        close(got, reference(x, w4, bias, wsc=wsc, sc=sc), what=f"ws + shortcut, variant {v}")
 
 
-@pytest.mark.parametrize("h,w", [(8, 8), (16, 16)])
+@pytest.mark.parametrize("h,w", [(8, 8), (16, 16), (8, 32)])
 def test_conv_ws_taps_and_borders_exact(ops, h, w):
     """A one-hot pixel through one-hot weights: out[y][x][n] = 1 exactly where (y, x) = pixel - tap offset lies in the map --
     every tap, both borders, every 16-pixel block, each wave's channel quarter (exact in bf16: single products of 1)."""
@@ -88,13 +96,14 @@ def test_conv_ws_taps_and_borders_exact(ops, h, w):
             w4 = torch.zeros(n, c, 3, 3)
             for t in range(9):
                 w4[t, ch, t // 3, t % 3] = 1.0                # output channel t picks tap t
-            got = ops.conv3x3_ws(x.to(torch.bfloat16).cuda(), pack_ws(w4).cuda(), torch.zeros(n).cuda(), n).float().cpu()
             want = torch.zeros(1, h, w, n)
             for t in range(9):
                 y, xx = py - (t // 3 - 1), px - (t % 3 - 1)
                 if 0 <= y < h and 0 <= xx < w:
                     want[0, y, xx, t] = 1.0
-            assert torch.equal(got, want), (py, px, ch)
+            for v in variants(h, w):
+                got = ops.conv3x3_ws(x.to(torch.bfloat16).cuda(), pack_ws(w4).cuda(), torch.zeros(n).cuda(), n, variant=v).float().cpu()
+                assert torch.equal(got, want), (py, px, ch, v)
 
 
 def test_conv_ws_matches_the_implicit_gemm_kernel(ops):
@@ -114,9 +123,10 @@ def test_conv_ws_is_bit_deterministic(ops):
     b, h, w, c, n = 1, 16, 16, 640, 1280
     x, w4 = rnd(b, h, w, c, seed=21).cuda(), rnd(n, c, 3, 3, scale=0.02, seed=22)
     wp, bias = pack_ws(w4).cuda(), rnd(n, seed=23, dtype=torch.float32).cuda()
-    first = ops.conv3x3_ws(x, wp, bias, n).clone()
-    for _ in range(20):
-        assert torch.equal(ops.conv3x3_ws(x, wp, bias, n), first)
+    for v in (1, 2):
+        first = ops.conv3x3_ws(x, wp, bias, n, variant=v).clone()
+        for _ in range(20):
+            assert torch.equal(ops.conv3x3_ws(x, wp, bias, n, variant=v), first)
 
 
 def test_conv_ws_rejects_shapes_it_does_not_take(ops):
@@ -124,6 +134,7 @@ def test_conv_ws_rejects_shapes_it_does_not_take(ops):
     from mvd_amd.packing import pack_ws
     w4 = rnd(16, 128, 3, 3)
     wp, bias = pack_ws(w4).cuda(), torch.zeros(16).cuda()
-    for shape in [(1, 12, 12, 128), (1, 32, 32, 128), (16, 8, 8, 128)]:      # 12-wide map, 32-wide map, more than 512 rows
+    for shape, v in [((1, 12, 12, 128), 0), ((1, 64, 64, 128), 0), ((32, 8, 8, 128), 0),      # 12-wide map, 64-wide map, more than 1024 rows
+                     ((1, 32, 32, 128), 2), ((1, 8, 8, 128), 2), ((1, 8, 8, 128), 3)]:        # forms that do not take the width / do not exist
         with pytest.raises(L.MvdError, match="conv_ws"):
-            ops.conv3x3_ws(rnd(*shape).cuda(), wp, bias, 16)
+            ops.conv3x3_ws(rnd(*shape).cuda(), wp, bias, 16, variant=v)

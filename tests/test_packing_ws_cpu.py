@@ -4,7 +4,7 @@ then [round][wave][lane][8] for the fused 1x1 shortcut, lane (i, h) = (lane & 15
 + 8 h + j] of tap 3 ky + kx -- and pack_unet registers the twins exactly where the engine looks for them."""
 import torch
 
-from mvd_amd.packing import WS_MAX_SHORTCUT, pack_ws
+from mvd_amd.packing import pack_ws
 
 
 def test_pack_ws_layout_by_definition():
@@ -33,19 +33,19 @@ def test_pack_ws_layout_by_definition():
                     assert torch.equal(short[rd, wave, lane], wsc[16 * ct + i, k0:k0 + 8])
 
 
-def test_pack_unet_registers_ws_twins_for_the_widest_level_only():
+def test_pack_unet_registers_ws_twins_for_every_level_but_the_first():
     from mvd_amd.config import UNetConfig
     from mvd_amd.packing import pack_unet
     from oracle import sd21_unet as OU                     # (test infrastructure: seeded weights of the tiny topology)
     cfg = UNetConfig.tiny()
     sd = OU.init_params(OU.UNetConfig.tiny(), seed=3)
     packed = pack_unet(sd, cfg, "cpu", adapter=False)
-    top = max(cfg.block_out_channels)
+    first = cfg.block_out_channels[0]
     seen = 0
     for key, cin, cout in cfg.resnets():
         has1, has2 = f"{key}.conv1.ws" in packed, f"{key}.conv2.ws" in packed
-        assert has1 == (cout == top and cin % 128 == 0), key
-        assert has2 == (cout == top and (cin == cout or (cin % 128 == 0 and cin <= WS_MAX_SHORTCUT))), key
+        assert has1 == (cout > first and cout % 128 == 0 and cin % 128 == 0), key
+        assert has2 == (cout > first and cout % 128 == 0 and cin == cout), key      # (fused-shortcut twins: MVD_WS_PACK_SHORTCUT=1 only)
         if has1:
             assert packed[f"{key}.conv1.ws"].numel() == cout * 9 * cin
         if has2:
