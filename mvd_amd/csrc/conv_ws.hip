@@ -104,6 +104,14 @@ MVD_DEVINL void ws_pass(const __amdgpu_buffer_rsrc_t rs_x, const unsigned (&svo)
       if (t + 1 < T) read_frags(t + 1, wn, xn);
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[rb], acc[rb], 0, 0, 0);
+      // Refill slot (half + t) for round rd + 2 -- but only once its fragment `wf` has RETURNED from LDS.  The asm "uses" wf (the
+      // compiler puts the lgkmcnt wait for that ds_read in front of it) and its memory clobber keeps the LDS-DMA behind it.
+      // Without it hipcc hoists the DMA to right behind the ds_read's ISSUE (no dependence it can see); a DMA whose 1 KB comes out of
+      // this CU's L1 -- a second row block of the same column tile -- can then land before a read that co-resident waves of
+      // another stream's kernel have delayed in the LDS queue: one k-chunk of the tile multiplies the wrong weights.  Seen only
+      // in the two-stream forward, in the one-tap (fused shortcut) passes, where read and refill sit in the same step
+      // (profiles/r04_probe_conv_ws_in_situ.log).
+      asm volatile("" ::"v"(__builtin_bit_cast(u32x4, wf)) : "memory");
       if constexpr (LA == 2) issue_w(rd + 2, t, half + t);
       if (t + 1 < T) {
         wf = wn;

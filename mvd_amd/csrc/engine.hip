@@ -404,11 +404,6 @@ struct Ctx {
              const bf16_t* sc0, const bf16_t* sc1, int scc0, int scc1, Act& out) {
     if (err) return err;
     if (dry || (g_debug_flags & 256) || slot.empty() || !has(slot)) return 0;
-    // The fused shortcut (conv2 | conv_shortcut) stays with the tiled kernels: in the two-stream forward -- and only there -- about one
-    // workgroup in 10^4 of those launches came out one k-chunk off (the in-situ comparison of probe builds, flag 32768:
-    // profiles/r04_probe_conv_ws_in_situ.log; not reproduced at op level, not cured by draining every round).  Probe builds can
-    // switch it back on for that comparison (flag 65536).
-    if (scc0 && !(g_debug_flags & 65536)) return 0;
     MvdWsArgs a; memset(&a, 0, sizeof(a));
     a.x = x.p; a.B = x.B; a.H = x.H; a.W = x.W; a.C = x.C; a.sc0 = sc0; a.sc1 = sc1; a.scc0 = scc0; a.scc1 = scc1;
     a.bias = bias; a.rowvec = rowvec; a.ld_rowvec = ld_rowvec; a.res = res; a.ldres = out.C; a.out = out.p; a.ldo = out.C;

@@ -18,7 +18,6 @@ from __future__ import annotations
 
 from typing import Dict
 
-import os
 
 import torch
 
@@ -114,11 +113,6 @@ def pack_xs(w: torch.Tensor, bias, geglu: bool = False, device=None) -> torch.Te
     return out.reshape(units, ks + 1, 64, 8).contiguous()
 
 
-# conv2 | conv_shortcut twins: the kernel takes them (tests/test_conv_ws_gpu.py) but the engine keeps the tiled kernels for those
-# launches (engine.hip try_ws: run-to-run differences in the two-stream forward), so by default they are not packed
-WS_PACK_SHORTCUT = bool(int(os.environ.get("MVD_WS_PACK_SHORTCUT", "0")))
-
-
 def pack_ws(w4: torch.Tensor, wsc=None, device=None) -> torch.Tensor:
     """conv weight ``[N][C][3][3]`` (+ 1x1 shortcut weight ``[N][Csc]`` or None) -> the weight stream of conv_ws.hip:
     per 16-channel column tile, the convolution's rounds ``[C/128][wave 4][tap 9][lane 64][8]`` then the shortcut's rounds
@@ -189,7 +183,7 @@ def pack_unet(sd: Dict[str, torch.Tensor], cfg: UNetConfig, device, adapter: boo
                 out[f"{key}.conv1.ws"] = pack_ws(sd[f"{key}.conv1.weight"], None, device)
             if cin == cout:
                 out[f"{key}.conv2.ws"] = pack_ws(sd[f"{key}.conv2.weight"], None, device)
-            elif cin % 128 == 0 and WS_PACK_SHORTCUT:
+            elif cin % 128 == 0:
                 out[f"{key}.conv2.ws"] = pack_ws(sd[f"{key}.conv2.weight"], sd[f"{key}.conv_shortcut.weight"].reshape(cout, cin), device)
         tw.append(sd[f"{key}.time_emb_proj.weight"].detach().float())
         tb.append(sd[f"{key}.time_emb_proj.bias"].detach().float())

@@ -45,7 +45,7 @@ def test_pack_unet_registers_ws_twins_for_every_level_but_the_first():
     for key, cin, cout in cfg.resnets():
         has1, has2 = f"{key}.conv1.ws" in packed, f"{key}.conv2.ws" in packed
         assert has1 == (cout > first and cout % 128 == 0 and cin % 128 == 0), key
-        assert has2 == (cout > first and cout % 128 == 0 and cin == cout), key      # (fused-shortcut twins: MVD_WS_PACK_SHORTCUT=1 only)
+        assert has2 == (cout > first and cout % 128 == 0 and (cin == cout or cin % 128 == 0)), key
         if has1:
             assert packed[f"{key}.conv1.ws"].numel() == cout * 9 * cin
         if has2:
