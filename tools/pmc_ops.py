@@ -6,7 +6,7 @@ import torch
 from mvd_amd import ops
 rnd = lambda *s: (torch.randn(*s, device="cuda") * 0.5).to(torch.bfloat16)
 B = 32
-which = os.environ.get("PMC_OPS", "attn,conv,lin,geglu,xs").split(",")
+which = os.environ.get("PMC_OPS", "attn,conv,lin,geglu,xs,ws").split(",")
 if "attn" in which:
     q, k, v = rnd(B, 4096, 320), rnd(B, 4096, 320), rnd(B, 4096, 320)
     for _ in range(3): ops.attention(q, k, v, 5, scale=0.0)      # the engine's form: prescaled q, LDS-DMA staging, dot2c denominators
@@ -31,4 +31,13 @@ if "xs" in which:      # the X-stationary kernels (gemm_xs.hip) at the 64x64-lev
         wp = pack_xs(torch.randn(n, 320, device="cuda") / math.sqrt(320), torch.randn(n, device="cuda"), geglu=geglu)
         r = rnd(131072, n) if res else None
         for _ in range(3): ops.linear_xs(a, wp, geglu=geglu, ln=ln, res=r)
+if "ws" in which:      # the weight-streaming convolution (conv_ws.hip) at batch 1: 8x8 / 16x16 (C = N = 1280) and 32x32 (C = N = 640),
+    import math        # a fresh copy of the weights per launch (a forward streams every weight once: cold)
+    from mvd_amd.packing import pack_ws
+    for hw, c in ((8, 1280), (16, 1280), (32, 640)):
+        x = rnd(1, hw, hw, c)
+        wp = pack_ws((torch.randn(c, c, 3, 3) / math.sqrt(9 * c)).to(torch.bfloat16)).cuda()
+        wps = [wp.clone() for _ in range(3)]
+        bias = torch.randn(c, device="cuda")
+        for i in range(3): ops.conv3x3_ws(x, wps[i], bias, c)
 torch.cuda.synchronize()

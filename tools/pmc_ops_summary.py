@@ -8,7 +8,7 @@ for d in sys.argv[1:]:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if "gemm_kernel" not in k and "gemm_pp_kernel" not in k and "attn_kernel" not in k and "gemm_xs_kernel" not in k: continue
+            if "gemm_kernel" not in k and "gemm_pp_kernel" not in k and "attn_kernel" not in k and "gemm_xs_kernel" not in k and "conv_ws_kernel" not in k: continue
             k = k.replace("(anonymous namespace)::", "").replace("void ", "")[:60]
             rows[k][r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
 for k, cs in rows.items():
