@@ -176,7 +176,8 @@ int mvd_op_linear_xs(const void* x, int ldx, const void* w_packed, int m, int k,
 /* The weight-streaming form of a resnet 3x3 convolution on ONE image's small map (mvd_amd/csrc/conv_ws.hip: batch 1, the 8x8 and
  * 16x16 levels -- 15-65 MB of weights for a few GFLOP):  out[B*H*W][n] = conv3x3(x; stride 1, pad 1) (+ [sc | sc2] . Wsc^T) + bias
  * + rowvec[image] + res.  w in {8, 16, 32}, h*w % 64 == 0, B*h*w <= 1024, c % 128 == 0, sc_c1 / sc_c2 % 128 == 0, n % 16 == 0;
- * w_packed from mvd_amd/packing.py::pack_ws; variant 0 = the launcher's choice of block height (1: 64 pixels, 2: 128 pixels on a 16-wide map).
+ * w_packed from mvd_amd/packing.py::pack_ws; variant 0 = the launcher's choice of block height (1: 64 pixels, 2: 128 pixels on a 16-wide map);
+ * + 16: nearest-neighbour 2x upsampling in front of the convolution (diffusers' Upsample2D: output 2h x 2w, 16 or 32 wide, no shortcut).
  * No workspace, no split-K: each workgroup streams its 16-channel weight panel once.
  * Replaces, for those shapes, the Conv2d of diffusers' ResnetBlock2D that /root/reference/src/models/mvd_unet.py:318-326 reaches
  * through UNet2DConditionModel.forward (the reference's own batch-1 loop: /root/reference/infer.py:111-122). */

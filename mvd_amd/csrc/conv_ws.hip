@@ -46,15 +46,18 @@ MVD_DEVINL void ws_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_wave_ba
 
 constexpr int WS_RING = 18;                    // 1 KB weight slots per wave: two rounds of nine taps
 
-template <int WD, int RB> struct WsGeom {
+// WD: OUTPUT map width; UPS: nearest-neighbour 2x upsampling in front of the convolution (the input map is WD / 2 wide)
+template <int WD, int RB, bool UPS> struct WsGeom {
   static constexpr int NBUF = 2;               // slab buffers per wave
   static constexpr int BM = 16 * RB;           // output pixels per workgroup (RB 16-pixel blocks)
   static constexpr int RO = BM / WD;           // output map rows per workgroup
-  static constexpr int SPX = (RO + 2) * WD;    // slab pixels: the output rows + one halo row above and below
+  static constexpr int WI = UPS ? WD / 2 : WD; // input map width
+  static constexpr int SR = UPS ? RO / 2 + 2 : RO + 2;   // input rows a block touches: its own + one halo row above and below
+  static constexpr int SPX = SR * WI;          // slab pixels
   static constexpr int NSL = SPX / 16;         // 1 KB DMA pieces per slab (16 pixels x 64 bytes)
   static constexpr int SLAB = SPX * 64 + 64;   // + the zero row
   static constexpr int WAVE_BYTES = WS_RING * 1024 + NBUF * SLAB;
-  static_assert(BM % WD == 0 && SPX % 16 == 0 && 4 * WAVE_BYTES <= 160 * 1024, "geometry");
+  static_assert(BM % WD == 0 && SPX % 16 == 0 && 4 * WAVE_BYTES <= 160 * 1024 && (!UPS || RO % 2 == 0), "geometry");
 };
 
 // One pass over `R` rounds of 128 input channels with T taps each.  svo[i]: the lane's global byte offset of slab piece i
@@ -134,9 +137,9 @@ MVD_DEVINL void ws_pass(const __amdgpu_buffer_rsrc_t rs_x, const unsigned (&svo)
   round(rd, std::integral_constant<int, 0>{});
 }
 
-template <int WD, int RB>
+template <int WD, int RB, bool UPS>
 __global__ __launch_bounds__(256) void conv_ws_kernel(const MvdWsArgs a) {
-  using G = WsGeom<WD, RB>;
+  using G = WsGeom<WD, RB, UPS>;
   constexpr int NSL = G::NSL, SLAB = G::SLAB, BM = G::BM, NBUF = G::NBUF;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
@@ -149,8 +152,10 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(const MvdWsArgs a) {
   const int g = blockIdx.x / (8 * nb), rem = blockIdx.x - g * 8 * nb;
   const int blk = rem >> 3, ct = g * 8 + (rem & 7);
   if (ct >= nct) return;
-  const int hw = a.H * WD, m0 = blk * BM;
+  const int OH = UPS ? 2 * a.H : a.H;                       // output map rows (a.H, a.W: the INPUT map)
+  const int hw = OH * WD, m0 = blk * BM;
   const int img = m0 / hw, oy0 = (m0 - img * hw) / WD;
+  const int iy_lo = UPS ? (oy0 - 1) >> 1 : oy0 - 1;         // input row of slab row 0 (may be -1: loaded from row 0, never read)
 
   unsigned char* const wbase = smem + wave * G::WAVE_BYTES;
   // zero rows of the slabs (a lane writes 4 bytes: 16 lanes per row)
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(const MvdWsArgs a) {
 
   // ---- the convolution: rounds of 128 channels x 9 taps
   {
-    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.x), 0, (int)((size_t)a.B * hw * a.C * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.x), 0, (int)((size_t)a.B * a.H * G::WI * a.C * 2), 0x00020000);
     unsigned svo[NSL];
 #pragma unroll
     for (int i = 0; i < NSL; ++i) {
@@ -174,10 +179,10 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(const MvdWsArgs a) {
       // a halo row outside the image is loaded from the nearest map row and never read (aoff points those taps at the zero
       // row): every lane of every piece is a real load.  An all-out-of-range LDS-DMA piece may retire ahead of its turn, and
       // the counted waits rest on in-order retirement (seen as run-to-run differences beside a second stream's kernels).
-      int iy = oy0 - 1 + q / WD;
-      const int ix = q % WD;
+      int iy = iy_lo + q / G::WI;
+      const int ix = q % G::WI;
       iy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy);
-      svo[i] = (unsigned)((((size_t)img * a.H + iy) * WD + ix) * a.C + 32 * wave + 8 * c) * 2u;
+      svo[i] = (unsigned)((((size_t)img * a.H + iy) * G::WI + ix) * a.C + 32 * wave + 8 * c) * 2u;
     }
     int aoff[9][RB];
 #pragma unroll
@@ -186,9 +191,11 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(const MvdWsArgs a) {
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) {
         const int p = 16 * rb + li;                                     // output pixel inside the block
-        const int ry = p / WD + dy, ix = p % WD + dx - 1;               // slab row (halo row 0 = map row oy0 - 1), map column
-        const int q = ry * WD + ix;
-        const bool inside = (unsigned)ix < (unsigned)WD && (unsigned)(oy0 - 1 + ry) < (unsigned)a.H;
+        // the tap's pixel in the (upsampled) map the convolution sees, then the input pixel behind it
+        const int uy = oy0 + p / WD + dy - 1, ux = p % WD + dx - 1;
+        const bool inside = (unsigned)ux < (unsigned)WD && (unsigned)uy < (unsigned)OH;
+        const int iy = UPS ? uy >> 1 : uy, ix = UPS ? ux >> 1 : ux;
+        const int q = (iy - iy_lo) * G::WI + ix;                        // slab pixel
         aoff[t][rb] = inside ? q * 64 + 16 * (lh ^ ((q >> 2) & 3)) : G::SPX * 64 + 16 * lh;
       }
     }
@@ -243,18 +250,18 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(const MvdWsArgs a) {
 }
 
 // variants: 1 = 64-pixel blocks (8-, 16-, 32-wide maps); 2 = 128-pixel blocks (16-wide maps: half the weight re-reads of variant 1)
-template <int WD, int RB>
+template <int WD, int RB, bool UPS>
 int launch_ws(const MvdWsArgs& a, hipStream_t s, bool* lds_set) {
-  using G = WsGeom<WD, RB>;
+  using G = WsGeom<WD, RB, UPS>;
   const int lds = 4 * G::WAVE_BYTES;
   if (!*lds_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<WD, RB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<WD, RB, UPS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) { mvd_set_error("conv_ws: hipFuncSetAttribute: %s", hipGetErrorString(e)); return -2; }
     *lds_set = true;
   }
   const int nb = a.M / G::BM, nct = a.N / 16;
   const int grid = ((nct + 7) / 8) * 8 * nb;
-  hipLaunchKernelGGL((conv_ws_kernel<WD, RB>), dim3(grid), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_ws_kernel<WD, RB, UPS>), dim3(grid), dim3(256), lds, s, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { mvd_set_error("conv_ws launch: %s", hipGetErrorString(e)); return -3; }
   return 0;
@@ -266,8 +273,9 @@ bool g_ws_lds_set[16][8];
 
 // The variant a launch takes (0: the shape is not taken).  `a.variant` > 0 forces one (tests, probes).
 static int ws_variant(const MvdWsArgs& a) {
-  const int hw = a.H * a.W;
-  const bool ok1 = (a.W == 8 || a.W == 16 || a.W == 32) && hw % 64 == 0, ok2 = a.W == 16 && hw % 128 == 0;
+  const int ow = a.ups ? 2 * a.W : a.W, hw = (a.ups ? 4 : 1) * a.H * a.W;          // output map width / pixels
+  const bool ok1 = a.ups ? (ow == 16 || ow == 32) && hw % 64 == 0 : (ow == 8 || ow == 16 || ow == 32) && hw % 64 == 0;
+  const bool ok2 = ow == 16 && hw % 128 == 0;
   if (a.variant == 1) return ok1 ? 1 : 0;
   if (a.variant == 2) return ok2 ? 2 : 0;
   if (a.variant) return 0;
@@ -277,8 +285,9 @@ static int ws_variant(const MvdWsArgs& a) {
 
 bool mvd_conv_ws_applicable(const MvdWsArgs& a) {
   if (!a.x || !a.w || !a.bias || !a.out || a.B <= 0 || a.H <= 0 || a.W <= 0) return false;
-  const int hw = a.H * a.W;
+  const int hw = (a.ups ? 4 : 1) * a.H * a.W;
   if (a.M != a.B * hw || a.M > 1024 || !ws_variant(a)) return false;
+  if (a.ups && (a.scc0 || a.scc1)) return false;
   if (a.C % 128 || a.C <= 0 || a.N % 16 || a.N <= 0) return false;
   if ((a.scc0 % 128) || (a.scc1 % 128) || (a.scc0 && !a.sc0) || (a.scc1 && !a.sc1) || (a.scc1 && !a.scc0)) return false;
   if ((a.ldo % 4) || a.ldo < a.N || (a.res && ((a.ldres % 4) || a.ldres < a.N))) return false;
@@ -292,15 +301,18 @@ bool mvd_conv_ws_applicable(const MvdWsArgs& a) {
 size_t mvd_conv_ws_packed_elems(int C, int sc, int N) { return (size_t)(N / 16) * (size_t)((C / 128) * 9 + sc / 128) * 4 * 512; }
 
 int mvd_launch_conv_ws(const MvdWsArgs& a, hipStream_t s) {
-  if (!mvd_conv_ws_applicable(a)) { mvd_set_error("conv_ws: shape not taken (B=%d H=%d W=%d C=%d sc=%d+%d N=%d M=%d variant=%d)", a.B, a.H, a.W, a.C, a.scc0, a.scc1, a.N, a.M, a.variant); return -1; }
+  if (!mvd_conv_ws_applicable(a)) { mvd_set_error("conv_ws: shape not taken (B=%d H=%d W=%d C=%d sc=%d+%d N=%d M=%d ups=%d variant=%d)", a.B, a.H, a.W, a.C, a.scc0, a.scc1, a.N, a.M, a.ups, a.variant); return -1; }
   int dev = 0;
   (void)hipGetDevice(&dev);
   bool* f = g_ws_lds_set[dev & 15];
-  switch (ws_variant(a) * 100 + a.W) {
-    case 108: return launch_ws<8, 4>(a, s, f + 0);
-    case 116: return launch_ws<16, 4>(a, s, f + 1);
-    case 132: return launch_ws<32, 4>(a, s, f + 2);
-    case 216: return launch_ws<16, 8>(a, s, f + 3);
+  switch ((a.ups ? 1000 : 0) + ws_variant(a) * 100 + (a.ups ? 2 * a.W : a.W)) {
+    case 108: return launch_ws<8, 4, false>(a, s, f + 0);
+    case 116: return launch_ws<16, 4, false>(a, s, f + 1);
+    case 132: return launch_ws<32, 4, false>(a, s, f + 2);
+    case 216: return launch_ws<16, 8, false>(a, s, f + 3);
+    case 1116: return launch_ws<16, 4, true>(a, s, f + 4);
+    case 1132: return launch_ws<32, 4, true>(a, s, f + 5);
+    case 1216: return launch_ws<16, 8, true>(a, s, f + 6);
   }
   mvd_set_error("conv_ws: no kernel for variant %d at map width %d", ws_variant(a), a.W);
   return -1;
@@ -310,7 +322,9 @@ extern "C" int mvd_op_conv3x3_ws(const void* x, int batch, int h, int w, int c, 
                                  const float* rowvec, int ld_rowvec, const void* res, const void* sc0, const void* sc1,
                                  int scc0, int scc1, void* out, int n, int variant, void* stream) {
   MvdWsArgs a; memset(&a, 0, sizeof(a));
-  a.x = (const bf16_t*)x; a.B = batch; a.H = h; a.W = w; a.C = c; a.M = batch * h * w; a.N = n; a.variant = variant;
+  a.ups = variant >= 16;                 // (variant + 16: nearest-neighbour 2x upsampling in front of the convolution)
+  variant &= 15;
+  a.x = (const bf16_t*)x; a.B = batch; a.H = h; a.W = w; a.C = c; a.M = batch * h * w * (a.ups ? 4 : 1); a.N = n; a.variant = variant;
   a.w = (const bf16_t*)w_packed; a.bias = bias; a.rowvec = rowvec; a.ld_rowvec = ld_rowvec;
   a.res = (const bf16_t*)res; a.ldres = n; a.sc0 = (const bf16_t*)sc0; a.sc1 = (const bf16_t*)sc1; a.scc0 = scc0; a.scc1 = scc1;
   a.out = (bf16_t*)out; a.ldo = n;

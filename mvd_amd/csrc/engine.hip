@@ -400,12 +400,12 @@ struct Ctx {
   // twin `<slot>.ws` (packing.pack_ws) is registered: batch 1 at the 8x8 / 16x16 / 32x32 levels is a weight stream, which the
   // implicit-GEMM kernels cut along K with a rendezvous between workgroups (21-63 us against 15-48 us, profiles/r04_probe_conv_ws.log).
   // Returns 1 when it launched, 0 when the caller should go on, < 0 on error.
-  int try_ws(const Act& x, const std::string& slot, const float* bias, const float* rowvec, int ld_rowvec, const bf16_t* res,
+  int try_ws(const Act& x, int ups, const std::string& slot, const float* bias, const float* rowvec, int ld_rowvec, const bf16_t* res,
              const bf16_t* sc0, const bf16_t* sc1, int scc0, int scc1, Act& out) {
     if (err) return err;
     if (dry || (g_debug_flags & 256) || slot.empty() || !has(slot)) return 0;
     MvdWsArgs a; memset(&a, 0, sizeof(a));
-    a.x = x.p; a.B = x.B; a.H = x.H; a.W = x.W; a.C = x.C; a.sc0 = sc0; a.sc1 = sc1; a.scc0 = scc0; a.scc1 = scc1;
+    a.x = x.p; a.B = x.B; a.H = x.H; a.W = x.W; a.C = x.C; a.ups = ups; a.sc0 = sc0; a.sc1 = sc1; a.scc0 = scc0; a.scc1 = scc1;
     a.bias = bias; a.rowvec = rowvec; a.ld_rowvec = ld_rowvec; a.res = res; a.ldres = out.C; a.out = out.p; a.ldo = out.C;
     a.M = out.rows(); a.N = out.C;
     // (debug flags, A/B only: 512 = maps of at most 256 pixels, 1024 = 64-pixel blocks everywhere, 2048 = no fused shortcut)
@@ -414,7 +414,10 @@ struct Ctx {
     if ((g_debug_flags & 2048) && scc0) return 0;
     if ((g_debug_flags & 4096) && nowait) return 0;             // (4096: not in the encoder pass of a two-stream forward; 8192: only there)
     if ((g_debug_flags & 8192) && !nowait) return 0;
-    if (out.H != x.H || out.W != x.W || out.B != x.B || a.M > 1024) return 0;     // (one 32x32 map at most: beyond, the tiled kernels have the FLOPs to win)
+    if (out.H != (ups ? 2 : 1) * x.H || out.W != (ups ? 2 : 1) * x.W || out.B != x.B || a.M > 1024) return 0;
+    // every 64-pixel row block streams its column tile's whole weight panel (from L2 at best): with 16 row blocks x 80 column tiles
+    // (the 16 -> 32 upsampling convolution, N = 1280) that is a tie with the tiled kernel (62.9 vs 60.5 us) -- not taken
+    if ((long)(a.M / 64) * (a.N / 16) > 1000) return 0;     // (one 32x32 map at most: beyond, the tiled kernels have the FLOPs to win)
     a.w = reinterpret_cast<const bf16_t*>(&a);                                     // (placeholder for the shape test)
     if (!mvd_conv_ws_applicable(a)) return 0;
     a.w = WB(slot, (int64_t)mvd_conv_ws_packed_elems(x.C, scc0 + scc1, out.C));
@@ -431,9 +434,9 @@ struct Ctx {
       const bf16_t* wold = WB(slot.substr(0, slot.size() - 1), (int64_t)out.C * (9 * x.C + scc0 + scc1));   // "<..>.convN.ws" -> "<..>.convN.w"
       if (wold) {
         const int saved = g_debug_flags; g_debug_flags |= 256;
-        conv3(x, 1, 0, wold, bias, rowvec, ld_rowvec, res, sc0, sc1, scc0, scc1, chk);
+        conv3(x, 1, ups, wold, bias, rowvec, ld_rowvec, res, sc0, sc1, scc0, scc1, chk);
         g_debug_flags = saved;
-        g_ws_ptrs[0] = (const char*)x.p; g_ws_lens[0] = (size_t)x.rows() * x.C * 2;
+        g_ws_ptrs[0] = (const char*)x.p; g_ws_lens[0] = (size_t)x.rows() * x.C * 2;   // (input rows)
         g_ws_ptrs[1] = (const char*)sc0; g_ws_lens[1] = (size_t)out.rows() * scc0 * 2;
         g_ws_ptrs[2] = (const char*)sc1; g_ws_lens[2] = (size_t)out.rows() * scc1 * 2;
         g_ws_ptrs[3] = (const char*)out.p; g_ws_lens[3] = (size_t)out.rows() * out.C * 2;
@@ -447,8 +450,8 @@ struct Ctx {
 
   int conv3(const Act& x, int stride, int ups, const bf16_t* w, const float* bias, const float* rowvec, int ld_rowvec,
             const bf16_t* res, const bf16_t* sc0, const bf16_t* sc1, int scc0, int scc1, Act& out, const std::string& ws = std::string()) {
-    if (!ws.empty() && stride == 1 && !ups) {
-      const int r = try_ws(x, ws, bias, rowvec, ld_rowvec, res, sc0, sc1, scc0, scc1, out);
+    if (!ws.empty() && stride == 1) {
+      const int r = try_ws(x, ups, ws, bias, rowvec, ld_rowvec, res, sc0, sc1, scc0, scc1, out);
       if (r) return r < 0 ? r : 0;
     }
     MvdGemmArgs g; memset(&g, 0, sizeof(g));
@@ -749,7 +752,7 @@ struct UNetPass {
       }
       if (i + 1 < n) {
         Act u = c.new_act(B, h.H * 2, h.W * 2, co, true);
-        CHECK(c.conv3(h, 1, 1, c.WB(bk + ".up.w", (int64_t)co * 9 * co), c.WF(bk + ".up.b", co), nullptr, 0, nullptr, nullptr, nullptr, 0, 0, u));
+        CHECK(c.conv3(h, 1, 1, c.WB(bk + ".up.w", (int64_t)co * 9 * co), c.WF(bk + ".up.b", co), nullptr, 0, nullptr, nullptr, nullptr, 0, 0, u, bk + ".up.ws"));
         h = u;
       }
       if (o.film) { Act res = h; CHECK(film("up_" + std::to_string(i), h, res)); h = res; }

@@ -98,14 +98,15 @@ int mvd_launch_gemm_xs(const MvdXsArgs& a, hipStream_t s);
 // out[M][N] = conv3x3(x; stride 1, pad 1) (+ dense shortcut rows sc0 | sc1) + bias + rowvec[image] + res, one image's 8-, 16- or
 // 32-wide map per 64- / 128-row block; weights host-packed by packing.pack_ws ([N / 16][round][wave][tap][64][8] bf16).
 struct MvdWsArgs {
-  const bf16_t* x; int B, H, W, C;            // NHWC bf16 input
+  const bf16_t* x; int B, H, W, C;            // NHWC bf16 input (H, W: the INPUT map)
+  int ups;                                    // 1: nearest-neighbour 2x upsampling in front of the convolution (output 2H x 2W; no shortcut)
   const bf16_t* sc0; const bf16_t* sc1; int scc0, scc1;   // dense segment [M][scc0] | [M][scc1] (conv_shortcut fused along K) or null
   const bf16_t* w;                            // packed weights (mvd_conv_ws_packed_elems elements)
   const float* bias;                          // [N]
   const float* rowvec; int ld_rowvec;         // per-image row vector [B][ld_rowvec] (time embedding) or null
   const bf16_t* res; int ldres;               // residual [M][ldres] or null
   bf16_t* out; int ldo;
-  int M, N;                                   // M = B * H * W
+  int M, N;                                   // M = output pixels = B * H * W (x 4 with ups)
   int variant;                                // 0: the launcher's choice; 1 / 2: force 64- / 128-pixel blocks (tests, probes; conv_ws.hip)
 };
 bool mvd_conv_ws_applicable(const MvdWsArgs& a);

@@ -75,19 +75,20 @@ def linear_xs(x, w_packed, geglu=False, ln=False, eps=1e-5, res=None, csplit=0, 
     return out
 
 
-def conv3x3_ws(x, w_packed, bias, n, rowvec=None, res=None, shortcut=None, shortcut2=None, variant=0):
+def conv3x3_ws(x, w_packed, bias, n, rowvec=None, res=None, shortcut=None, shortcut2=None, variant=0, upsample=False):
     """The weight-streaming 3x3 convolution of small maps (conv_ws.hip): x (B, H, W, C) bf16 with W in {8, 16, 32}, H * W % 64 == 0,
-    B * H * W <= 1024, C % 128 == 0; ``variant`` 0 = the launcher's choice, 1 / 2 force 64- / 128-pixel blocks; ``w_packed`` from packing.pack_ws (conv weight [n][C][3][3] and, optionally, the 1x1
+    B * H * W <= 1024, C % 128 == 0; ``variant`` 0 = the launcher's choice, 1 / 2 force 64- / 128-pixel blocks; ``upsample``: nearest 2x in front of the
+    convolution (diffusers' Upsample2D; output 2H x 2W of width 16 or 32, no shortcut); ``w_packed`` from packing.pack_ws (conv weight [n][C][3][3] and, optionally, the 1x1
     shortcut weight over ``shortcut`` | ``shortcut2`` rows); stride 1, padding 1.  Returns (B, H, W, n) bf16."""
     _bf16(x, w_packed, res, shortcut, shortcut2)
     b, h, w, c = x.shape
-    out = torch.empty(b, h, w, n, device=x.device, dtype=torch.bfloat16)
+    out = torch.empty(b, 2 * h if upsample else h, 2 * w if upsample else w, n, device=x.device, dtype=torch.bfloat16)
     assert bias.dtype == torch.float32 and bias.numel() == n and x.is_contiguous()
     assert rowvec is None or (rowvec.dtype == torch.float32 and rowvec.stride(1) == 1)
     pp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
     L.call("mvd_op_conv3x3_ws", _p(x), b, h, w, c, _p(w_packed), _p(bias), pp(rowvec), rowvec.stride(0) if rowvec is not None else 0,
            pp(res), pp(shortcut), pp(shortcut2), shortcut.shape[-1] if shortcut is not None else 0,
-           shortcut2.shape[-1] if shortcut2 is not None else 0, _p(out), n, int(variant), _s())
+           shortcut2.shape[-1] if shortcut2 is not None else 0, _p(out), n, int(variant) + (16 if upsample else 0), _s())
     return out
 
 

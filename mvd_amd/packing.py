@@ -256,6 +256,9 @@ def pack_unet(sd: Dict[str, torch.Tensor], cfg: UNetConfig, device, adapter: boo
         out[f"down_blocks.{i}.down.w"] = _bf(_conv_w(sd[f"down_blocks.{i}.downsamplers.0.conv.weight"]), device)
         out[f"down_blocks.{i}.down.b"] = _f32(sd[f"down_blocks.{i}.downsamplers.0.conv.bias"], device)
         out[f"up_blocks.{i}.up.w"] = _bf(_conv_w(sd[f"up_blocks.{i}.upsamplers.0.conv.weight"]), device)
+        wu = sd[f"up_blocks.{i}.upsamplers.0.conv.weight"]
+        if wu.shape[0] > cfg.block_out_channels[0] and wu.shape[0] % 128 == 0 and wu.shape[1] % 128 == 0:
+            out[f"up_blocks.{i}.up.ws"] = pack_ws(wu, None, device)            # conv_ws.hip with the 2x upsampling in front
         out[f"up_blocks.{i}.up.b"] = _f32(sd[f"up_blocks.{i}.upsamplers.0.conv.bias"], device)
     out["conv_norm_out.g"] = _f32(sd["conv_norm_out.weight"], device)
     out["conv_norm_out.b"] = _f32(sd["conv_norm_out.bias"], device)

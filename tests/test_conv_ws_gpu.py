@@ -83,6 +83,38 @@ def test_conv_ws_fused_shortcut(ops, b, h, w, c, n, s0, s1):
         close(got, reference(x, w4, bias, wsc=wsc, sc=sc), what=f"ws + shortcut, variant {v}")
 
 
+@pytest.mark.parametrize("b,h,w,c,n", [(1, 8, 8, 1280, 1280), (1, 16, 16, 256, 64), (2, 4, 8, 128, 48), (1, 2, 16, 128, 16), (3, 8, 8, 128, 32)])
+def test_conv_ws_upsample_in_front(ops, b, h, w, c, n):
+    """diffusers' Upsample2D: nearest-neighbour 2x, then the 3x3 convolution -- the slab holds the INPUT rows, a tap reads
+    pixel (uy >> 1, ux >> 1).  Output maps 16 and 32 wide, both block heights where they apply."""
+    from mvd_amd.packing import pack_ws
+    x, w4 = rnd(b, h, w, c, seed=31), rnd(n, c, 3, 3, scale=1 / math.sqrt(9 * c), seed=32)
+    bias = rnd(n, seed=33, dtype=torch.float32)
+    up = F.interpolate(x.float().permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest")
+    want = F.conv2d(up, w4.float(), padding=1).permute(0, 2, 3, 1) + bias
+    wp = pack_ws(w4).cuda()
+    for v in variants(2 * h, 2 * w):
+        close(ops.conv3x3_ws(x.cuda(), wp, bias.cuda(), n, variant=v, upsample=True), want, what=f"ws upsample, variant {v}")
+
+
+def test_conv_ws_upsample_taps_exact(ops):
+    """one-hot input pixel and one-hot weights under the upsampling: exact 0 / 1 pattern at every border"""
+    from mvd_amd.packing import pack_ws
+    h = w = 8
+    c, n = 128, 16
+    for (py, px) in [(0, 0), (h - 1, w - 1), (3, 0), (0, w - 1), (4, 5)]:
+        x = torch.zeros(1, h, w, c)
+        x[0, py, px, 70] = 1.0
+        w4 = torch.zeros(n, c, 3, 3)
+        for t in range(9):
+            w4[t, 70, t // 3, t % 3] = 1.0
+        up = F.interpolate(x.permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest")
+        want = F.conv2d(up, w4, padding=1).permute(0, 2, 3, 1)
+        for v in (1, 2):
+            got = ops.conv3x3_ws(x.to(torch.bfloat16).cuda(), pack_ws(w4).cuda(), torch.zeros(n).cuda(), n, variant=v, upsample=True).float().cpu()
+            assert torch.equal(got, want), (py, px, v)
+
+
 @pytest.mark.parametrize("h,w", [(8, 8), (16, 16), (8, 32)])
 def test_conv_ws_taps_and_borders_exact(ops, h, w):
     """A one-hot pixel through one-hot weights: out[y][x][n] = 1 exactly where (y, x) = pixel - tap offset lies in the map --

@@ -38,7 +38,10 @@ for name, count, hw, cin, sc, n in (("L3 conv 1280->1280", 9, 8, 1280, 0, 1280),
                                     ("L2 conv1 640->1280", 1, 16, 640, 0, 1280), ("L2 conv 1280->1280", 3, 16, 1280, 0, 1280), ("L2 conv2+sc 1280 (+640)", 1, 16, 1280, 640, 1280),
                                     ("L2 conv1 2560->1280", 2, 16, 2560, 0, 1280), ("L2 conv2+sc 1280 (+2560)", 2, 16, 1280, 2560, 1280),
                                     ("L2 conv1 1920->1280", 1, 16, 1920, 0, 1280), ("L2 conv2+sc 1280 (+1920)", 1, 16, 1280, 1920, 1280),
-                                    ("L1 conv 640->640", 2, 32, 640, 0, 640), ("L1 conv1 1280->640", 1, 32, 1280, 0, 640), ("L1 conv1 1920->640", 1, 32, 1920, 0, 640)):
+                                    ("L1 conv 640->640", 2, 32, 640, 0, 640), ("L1 conv1 1280->640", 1, 32, 1280, 0, 640), ("L1 conv1 1920->640", 1, 32, 1920, 0, 640),
+                                    ("L3 up 8->16 1280", 1, -8, 1280, 0, 1280), ("L2 up 16->32 1280", 1, -16, 1280, 0, 1280)):
+    ups = hw < 0          # (negative size: the INPUT map of an upsampling convolution)
+    hw = abs(hw)
     x = rnd(1, hw, hw, cin)
     w4 = (torch.randn(n, cin, 3, 3, generator=g) / math.sqrt(9 * cin)).to(torch.bfloat16)
     wsc = (torch.randn(n, sc, generator=g) / math.sqrt(sc)).to(torch.bfloat16) if sc else None
@@ -51,16 +54,18 @@ for name, count, hw, cin, sc, n in (("L3 conv 1280->1280", 9, 8, 1280, 0, 1280),
     if sc:
         wold = torch.cat([wold, wsc.float()], 1)
     wold = wold.to(torch.bfloat16).to(dev)
-    M, K = hw * hw, 9 * cin + sc
+    M, K = hw * hw * (4 if ups else 1), 9 * cin + sc
     sk = ops.engine_splitk(M, n, K)
     warm = [x] + [t for t in (s0, s1) if t is not None]
-    old = lambda: ops.conv3x3(x, wold, bias, rowvec=rowvec, shortcut=s0, shortcut2=s1, splitk=sk)   # noqa: E731
+    if ups:
+        rowvec = None
+    old = lambda: ops.conv3x3(x, wold, bias, rowvec=rowvec, shortcut=s0, shortcut2=s1, splitk=sk, upsample=ups)   # noqa: E731
     b = old().float()
     t_old = bracket(old, warm) - EMPTY
     mb = wp.numel() * 2 / 1e6
     res = {}
     for v in (0, 1, 2):
-        new = lambda: ops.conv3x3_ws(x, wp, bias, n, rowvec=rowvec, shortcut=s0, shortcut2=s1, variant=v)   # noqa: E731
+        new = lambda: ops.conv3x3_ws(x, wp, bias, n, rowvec=rowvec, shortcut=s0, shortcut2=s1, variant=v, upsample=ups)   # noqa: E731
         try:
             a = new().float()
         except L.MvdError:
