@@ -4,6 +4,7 @@ libmvd_hip.so.  There is no CPU path: constructing an engine without a GPU raise
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -23,11 +24,15 @@ def _stream():
 
 class MVDEngine:
     def __init__(self, cfg: UNetConfig, cam_output_dim: int = 1024, cam_hidden_dim: int = 512,
-                 simple_cam_encoder: bool = False, cam_modulation_strength: float = 0.2, device="cuda:0"):
+                 simple_cam_encoder: bool = False, cam_modulation_strength: float = 0.2, device="cuda:0",
+                 small_batch_twins: Optional[bool] = None):
         if not torch.cuda.is_available():
             raise L.MvdError("MVDEngine needs a MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
         self.cfg = cfg
         self.device = torch.device(device)
+        # second packed copies only a batch-1 forward reads (packing.pack_unet): on unless MVD_PACK_SMALL_BATCH_TWINS=0
+        self.small_batch_twins = (os.environ.get("MVD_PACK_SMALL_BATCH_TWINS", "1") != "0") if small_batch_twins is None \
+            else bool(small_batch_twins)
         c = L.mvd_config_t()
         c.in_channels, c.out_channels, c.num_levels = cfg.in_channels, cfg.out_channels, cfg.num_levels
         for i in range(cfg.num_levels):
@@ -68,7 +73,7 @@ class MVDEngine:
     def load_base(self, sd: Dict[str, torch.Tensor], adapter: bool, ref_scale: float):
         """``sd``: diffusers keys of base_unet (+ ``...processor.*`` adapter keys when ``adapter``)."""
         with torch.no_grad():
-            self._register(0, pack_unet(sd, self.cfg, self.device, adapter, ref_scale))
+            self._register(0, pack_unet(sd, self.cfg, self.device, adapter, ref_scale, self.small_batch_twins))
 
     def load_camera(self, sd: Dict[str, torch.Tensor]):
         with torch.no_grad():
@@ -76,7 +81,7 @@ class MVDEngine:
 
     def load_image_encoder(self, sd: Dict[str, torch.Tensor]):
         with torch.no_grad():
-            self._register(1, pack_unet(sd, self.cfg, self.device, False))
+            self._register(1, pack_unet(sd, self.cfg, self.device, False, 0.0, self.small_batch_twins))
         self.share_encoder_weights(False)
 
     def share_encoder_weights(self, enable: bool = True):

@@ -137,6 +137,7 @@ def pack_ws(w4: torch.Tensor, wsc=None, device=None) -> torch.Tensor:
 # LayerNorm fold: only the 64x64 / 32x32 levels (C = 320 / 640 in SD-2.1) ever reach the fused kernel (it needs >= 200
 # tiles of 256x320, i.e. many rows); deeper levels keep ln_kernel + the plain GEMM and get no folded twin
 LN_FOLD_MAX_C = 1 << 30     # every level: the small-M kernels (batch 1) fold at C = 1280 too (the M = 32-images kernels stop at 640)
+LN_FOLD_LARGE_BATCH_MAX_C = 640   # what the many-images kernels (gemm_pp / gemm_xs: mvd_gemm_ln_fold_ok) ever read
 
 
 def fold_layernorm(w: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, bias, device):
@@ -151,8 +152,15 @@ def fold_layernorm(w: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, bia
     return wf.to(device).contiguous(), torch.stack([c1, c2], 0).to(device=device, dtype=torch.float32).contiguous()
 
 
-def pack_unet(sd: Dict[str, torch.Tensor], cfg: UNetConfig, device, adapter: bool, ref_scale: float = 0.0) -> Dict[str, torch.Tensor]:
-    """``sd`` holds diffusers keys (no wrapper prefix) and, when ``adapter``, the ``...processor.*`` keys."""
+def pack_unet(sd: Dict[str, torch.Tensor], cfg: UNetConfig, device, adapter: bool, ref_scale: float = 0.0,
+              small_batch_twins: bool = True) -> Dict[str, torch.Tensor]:
+    """``sd`` holds diffusers keys (no wrapper prefix) and, when ``adapter``, the ``...processor.*`` keys.
+
+    ``small_batch_twins=False`` leaves out the second copies only a batch-1 forward reads -- the weight-streaming ``.ws``
+    convolution twins (conv_ws.hip) and the LayerNorm-folded ``.wf/.cf`` twins above C = 640 (gemm_sm.hip): ~1.4 GB per SD-2.1
+    weight set.  The engine looks every twin up by name and takes the tiled convolution / ln_kernel + plain GEMM route when it is
+    absent (engine.hip ``try_ws`` / ``ln_gemm``), so a deployment that only ever runs many-image batches loses nothing."""
+    fold_max_c = LN_FOLD_MAX_C if small_batch_twins else LN_FOLD_LARGE_BATCH_MAX_C
     out: Dict[str, torch.Tensor] = {}
     w_in = _conv_w(sd["conv_in.weight"], tap_major=True)                       # [C0][9*Cin] -> zero padded to K = 64 (one MFMA slab)
     out["conv_in.w"] = _bf(torch.nn.functional.pad(w_in, (0, 64 - w_in.shape[1])), device)
@@ -178,7 +186,7 @@ def pack_unet(sd: Dict[str, torch.Tensor], cfg: UNetConfig, device, adapter: boo
         out[f"{key}.conv2.b"] = _f32(b2, device)
         # weight-streaming twins (conv_ws.hip) for every level but the first -- the 32x32, 16x16 and 8x8 maps of a 64x64 latent,
         # where a batch-1 launch is a weight stream (input / output widths the kernel takes: % 128 and % 16)
-        if cout > cfg.block_out_channels[0] and cout % 128 == 0:
+        if small_batch_twins and cout > cfg.block_out_channels[0] and cout % 128 == 0:
             if cin % 128 == 0:
                 out[f"{key}.conv1.ws"] = pack_ws(sd[f"{key}.conv1.weight"], None, device)
             if cin == cout:
@@ -229,7 +237,7 @@ def pack_unet(sd: Dict[str, torch.Tensor], cfg: UNetConfig, device, adapter: boo
         ff1_w, ff1_b = _geglu_rows(f(f"{b}.ff.net.0.proj.weight")), _geglu_rows(f(f"{b}.ff.net.0.proj.bias"))
         out[f"{key}.ff1.w"] = _bf(ff1_w, device)
         out[f"{key}.ff1.b"] = _f32(ff1_b, device)
-        if C <= LN_FOLD_MAX_C:
+        if C <= fold_max_c:
             for slot, w, bias, i in ((f"{key}.attn1.qkv", torch.cat(qkv, 0), None, 1), (f"{key}.attn2.q", torch.cat(q2, 0), None, 2),
                                      (f"{key}.ff1", ff1_w, ff1_b, 3)):
                 out[f"{slot}.wf"], out[f"{slot}.cf"] = fold_layernorm(w, f(f"{b}.norm{i}.weight"), f(f"{b}.norm{i}.bias"), bias, device)
@@ -257,7 +265,7 @@ def pack_unet(sd: Dict[str, torch.Tensor], cfg: UNetConfig, device, adapter: boo
         out[f"down_blocks.{i}.down.b"] = _f32(sd[f"down_blocks.{i}.downsamplers.0.conv.bias"], device)
         out[f"up_blocks.{i}.up.w"] = _bf(_conv_w(sd[f"up_blocks.{i}.upsamplers.0.conv.weight"]), device)
         wu = sd[f"up_blocks.{i}.upsamplers.0.conv.weight"]
-        if wu.shape[0] > cfg.block_out_channels[0] and wu.shape[0] % 128 == 0 and wu.shape[1] % 128 == 0:
+        if small_batch_twins and wu.shape[0] > cfg.block_out_channels[0] and wu.shape[0] % 128 == 0 and wu.shape[1] % 128 == 0:
             out[f"up_blocks.{i}.up.ws"] = pack_ws(wu, None, device)            # conv_ws.hip with the 2x upsampling in front
         out[f"up_blocks.{i}.up.b"] = _f32(sd[f"up_blocks.{i}.upsamplers.0.conv.bias"], device)
     out["conv_norm_out.g"] = _f32(sd["conv_norm_out.weight"], device)

@@ -299,6 +299,17 @@ def test_small_m_kill_switch_falls_back_instead_of_failing():
     assert stats["finite"] and stats["rel_l2"] <= TOL_L2 and stats["max_rel"] <= TOL_MAX, stats
 
 
+def test_lean_packing_without_small_batch_twins_falls_back(monkeypatch):
+    """MVD_PACK_SMALL_BATCH_TWINS=0 leaves out the ``.ws`` and the C > 640 ``.wf/.cf`` copies; the engine must
+    then take the tiled convolutions / ln_kernel + plain GEMM at batch 1 and stay within the same tolerance."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from tests.parity_util import run_tiny_parity
+    monkeypatch.setenv("MVD_PACK_SMALL_BATCH_TWINS", "0")
+    stats = run_tiny_parity(batch=1, verbose=True)
+    assert stats["finite"] and stats["rel_l2"] <= TOL_L2 and stats["max_rel"] <= TOL_MAX, stats
+
+
 def test_sd21_full_size_parity_768():
     """The reference's own default: 768 x 768 images = 96 x 96 latents (infer.py:187, config/train_config.yaml sample_size 96), full
     SD-2.1 shapes, B = 1, camera FiLM + cross-view adapter, cold forward: 9216 tokens at the first level (the split-KV attention,

@@ -52,3 +52,28 @@ def test_pack_unet_registers_ws_twins_for_every_level_but_the_first():
             assert packed[f"{key}.conv2.ws"].numel() == cout * (9 * cout + (cin if cin != cout else 0))
         seen += has1 + has2
     assert seen > 0
+
+
+def test_pack_unet_without_small_batch_twins_keeps_only_what_many_image_batches_read():
+    """the copies only a batch-1 forward reads are optional.  Off: no ``.ws`` twin anywhere, LayerNorm-folded
+    twins only up to C = 640 (what mvd_gemm_ln_fold_ok takes), every other slot bit-identical."""
+    import torch
+    from mvd_amd.config import UNetConfig
+    from mvd_amd.packing import LN_FOLD_LARGE_BATCH_MAX_C, pack_unet
+    from oracle import sd21_unet as OU
+    cfg = UNetConfig.tiny()
+    sd = OU.init_params(OU.UNetConfig.tiny(), seed=3)
+    full = pack_unet(sd, cfg, "cpu", adapter=False)
+    lean = pack_unet(sd, cfg, "cpu", adapter=False, small_batch_twins=False)
+    assert set(lean) <= set(full)
+    dropped = set(full) - set(lean)
+    assert dropped and all(k.endswith((".ws", ".wf", ".cf")) for k in dropped), sorted(dropped)[:5]
+    assert not any(k.endswith(".ws") for k in lean)
+    for key, _feat, C, _heads in cfg.transformers():
+        for slot in (f"{key}.attn1.qkv", f"{key}.attn2.q", f"{key}.ff1"):
+            assert (f"{slot}.wf" in lean) == (C <= LN_FOLD_LARGE_BATCH_MAX_C), slot
+            assert f"{slot}.wf" in full
+    for k, t in lean.items():
+        assert torch.equal(t, full[k]), k
+    nbytes = lambda d: sum(t.numel() * t.element_size() for t in d.values())   # noqa: E731
+    assert nbytes(lean) < nbytes(full)
