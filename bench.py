@@ -338,8 +338,7 @@ def launch_dry_run(args, D):
                                                "backend": D.collective_library(), "rehearsal": True},
                           "ranks_seen": idents, "distinct_gpus": D.distinct_devices(idents),
                           "broadcast_ok": bool(ok), "dry_run": True}), flush=True)
-    if torch.distributed.is_initialized():
-        torch.distributed.destroy_process_group()
+    D.shutdown()
     return 0 if ok else 1
 
 
@@ -583,6 +582,7 @@ def main():
             "kernel_classes": classes,
         }
         print(json.dumps(line), flush=True)
+    D.shutdown()        # (after rank 0's line is out: a clean exit of every rank, no "process group not destroyed" noise)
 
 
 if __name__ == "__main__":

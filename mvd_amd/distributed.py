@@ -221,6 +221,19 @@ def barrier():
         dist.barrier()
 
 
+def shutdown():
+    """Leave the process group in step with the other ranks (barrier, then destroy); never raises -- by the time this runs the
+    results are out, and a rank that cannot say goodbye must not turn a finished run into a failed one."""
+    if not dist.is_initialized():
+        return
+    try:
+        if dist.get_world_size() > 1:
+            dist.barrier()
+        dist.destroy_process_group()
+    except Exception as ex:          # pragma: no cover
+        print(f"warning: process group shutdown: {ex}", flush=True, file=__import__("sys").stderr)
+
+
 def collective_library() -> str:
     """Name + version of the collective library behind the process group (what carried the weight broadcast): "rccl 2.x.y"
     for backend nccl on ROCm (torch.cuda.nccl.version() IS RCCL's there), "gloo" for the CPU rehearsal backend."""
@@ -267,10 +280,15 @@ def gather_identities(local_rank: int) -> List[Dict[str, object]]:
 
 
 def distinct_devices(idents: Sequence[Dict[str, object]]) -> int:
-    """Number of different GPUs among the gathered identities (by UUID, else PCI bus id, else device index)."""
+    """Number of different GPUs among the gathered identities: two ranks share a GPU only if EVERYTHING the runtime reports
+    about their devices agrees (UUID, PCI bus / device id, bound device index) -- a runtime that hands every device the same
+    UUID must not make eight GPUs count as one.  Without a GPU (CPU rehearsal) the process id stands in."""
     keys = []
     for d in idents:
-        keys.append(d.get("uuid") or d.get("pci_bus_id") or ("dev", d.get("device", d.get("pid"))))
+        if "device" in d:
+            keys.append(("gpu", d.get("uuid"), d.get("pci_bus_id"), d.get("pci_device_id"), d.get("device")))
+        else:
+            keys.append(("pid", d.get("pid")))
     return len(set(keys))
 
 

@@ -40,6 +40,10 @@ def test_device_identity_helpers():
     two = [{"local_rank": 0, "uuid": "GPU-a", "device": 0}, {"local_rank": 1, "uuid": "GPU-b", "device": 1}]
     assert D.distinct_devices(same) == 1 and D.distinct_devices(two) == 2
     assert D.distinct_devices([{"device": 0}, {"device": 1}, {"device": 1}]) == 2
+    # a runtime that reports ONE uuid for every device must not make eight GPUs count as one
+    clones = [{"local_rank": r, "uuid": "GPU-a", "pci_bus_id": str(10 + r), "device": r} for r in range(8)]
+    assert D.distinct_devices(clones) == 8
+    assert D.distinct_devices([{"local_rank": 0, "pid": 11}, {"local_rank": 1, "pid": 12}]) == 2    # CPU rehearsal
     D.check_enough_devices(8, rehearsal=True)                        # a rehearsal may oversubscribe one GPU
     D.check_enough_devices(8)                                        # no GPU visible: nothing to check (CPU control-flow tests)
 
