@@ -116,9 +116,21 @@ class MVDPipeline:
     def prepare_latents(self, batch_size, num_channels_latents, height, width, dtype, device, generator, latents=None):
         """StableDiffusionPipeline.prepare_latents: N(0,1) of the latent shape times ``init_noise_sigma``."""
         shape = (batch_size, num_channels_latents, int(height) // self.vae_scale_factor, int(width) // self.vae_scale_factor)
+        if isinstance(generator, (list, tuple)):
+            # diffusers' prepare_latents / randn_tensor: one generator per latent (the signature's List[torch.Generator],
+            # pipeline.py:22) -- a list of another length is an error, each row is drawn from its own generator
+            if len(generator) != batch_size:
+                raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective "
+                                 f"batch size of {batch_size}. Make sure the batch size matches the length of the generators.")
+            if len(generator) == 1:
+                generator = generator[0]
         if latents is None:
-            gdev = generator.device if isinstance(generator, torch.Generator) else device
-            latents = torch.randn(shape, generator=generator, device=gdev, dtype=torch.float32).to(device)
+            if isinstance(generator, (list, tuple)):
+                rows = [torch.randn((1,) + shape[1:], generator=g, device=g.device, dtype=torch.float32).to(device) for g in generator]
+                latents = torch.cat(rows, dim=0)
+            else:
+                gdev = generator.device if isinstance(generator, torch.Generator) else device
+                latents = torch.randn(shape, generator=generator, device=gdev, dtype=torch.float32).to(device)
         return latents.to(device) * self.scheduler.init_noise_sigma
 
     @staticmethod

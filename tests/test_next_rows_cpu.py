@@ -60,3 +60,28 @@ def test_lightning_checkpoint_key_rewrite(tmp_path):
     missing, unexpected = load_lightning_checkpoint(model, str(path))
     assert missing == [] and unexpected == ["not_a_real_key"]
     torch.testing.assert_close(model.state_dict()["image_encoder.unet.conv_in.weight"], params["image_encoder.unet.conv_in.weight"])
+
+
+def test_prepare_latents_generator_list_follows_diffusers_randn_tensor():
+    """pipeline.py:22 takes ``generator: Union[torch.Generator, List[torch.Generator]]`` and hands it to the base class's
+    ``prepare_latents`` (:87-95): one generator per latent row, a list of another length raises ValueError, a one-element list
+    is that generator.  Host logic only (no engine)."""
+    import pytest
+    from types import SimpleNamespace
+    from mvd_amd.pipeline import MVDPipeline
+    pipe = MVDPipeline(unet=SimpleNamespace(), scheduler=SimpleNamespace(init_noise_sigma=2.0))
+    gens = [torch.Generator().manual_seed(s) for s in (11, 12, 13)]
+    got = pipe.prepare_latents(3, 4, 64, 48, torch.float32, torch.device("cpu"), gens)
+    assert got.shape == (3, 4, 8, 6)
+    for i, s in enumerate((11, 12, 13)):
+        want = 2.0 * torch.randn(1, 4, 8, 6, generator=torch.Generator().manual_seed(s))
+        assert torch.equal(got[i:i + 1], want)
+    with pytest.raises(ValueError, match="list of generators of length 2"):
+        pipe.prepare_latents(3, 4, 64, 48, torch.float32, torch.device("cpu"), gens[:2])
+    one = pipe.prepare_latents(1, 4, 64, 48, torch.float32, torch.device("cpu"), [torch.Generator().manual_seed(5)])
+    assert torch.equal(one, 2.0 * torch.randn(1, 4, 8, 6, generator=torch.Generator().manual_seed(5)))
+    two = pipe.prepare_latents(2, 4, 64, 48, torch.float32, torch.device("cpu"), torch.Generator().manual_seed(5))
+    assert torch.equal(two, 2.0 * torch.randn(2, 4, 8, 6, generator=torch.Generator().manual_seed(5)))
+    # caller-provided latents are only scaled (prepare_latents' latents= branch)
+    lat = torch.ones(1, 4, 8, 6)
+    assert torch.equal(pipe.prepare_latents(1, 4, 64, 48, torch.float32, torch.device("cpu"), None, latents=lat), 2.0 * lat)
