@@ -443,7 +443,8 @@ def main():
         model.mark_weights_changed()
     eng = model._sync_engine()
     bc = D.broadcast_engine_weights(eng, 0)
-    idents = D.gather_identities(local)                 # every rank's GPU, for rank 0's line
+    # every rank's GPU, for rank 0's line (LOCAL_RANK as the launcher gave it: a rehearsal binds every rank to device 0)
+    idents = D.gather_identities(int(os.environ.get("LOCAL_RANK", local)))
     weight_bytes = eng.weight_bytes()
     for p in model.parameters():           # fp32 masters are no longer needed on the device
         p.data = torch.empty(0, device=dev)
