@@ -314,6 +314,8 @@ def test_sd21_full_size_parity_768():
     """The reference's own default: 768 x 768 images = 96 x 96 latents (infer.py:187, config/train_config.yaml sample_size 96), full
     SD-2.1 shapes, B = 1, camera FiLM + cross-view adapter, cold forward: 9216 tokens at the first level (the split-KV attention,
     the small-M GEMMs at M = 9216 / 2304 / 576 / 144) under the checker.  The oracle needs ~40 s of CPU."""
+    from tests.conftest import oracle_time_budget
+    oracle_time_budget(45)
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from tests.parity_util import run_tiny_parity
@@ -328,6 +330,8 @@ def test_sd21_full_size_denoise_loop_cfg():
     per forward under CFG: the Q4 re-chunking of the reference tokens), camera + image conditioning, the per-step Fourier
     projection pinned, the same ancestral noise draws as ``oracle/scheduler.denoise_loop``.  Quantifies the error growth over
     chained bf16 forwards (one forward: rel-L2 ~1e-2): stated tolerance rel-L2 <= 5e-2 on the final latents."""
+    from tests.conftest import oracle_time_budget
+    oracle_time_budget(130)
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from mvd_amd.pipeline import MVDDenoiser

@@ -199,3 +199,18 @@ def test_utils_log_debug_and_dirs(tmp_path):
     log_debug(str(f), "hello")
     assert f.read_text().rstrip().endswith(" - hello")
     log_debug(str(tmp_path / "missing_dir" / "x.log"), "does not raise")
+
+
+def test_gpu_session_time_budget_guard(monkeypatch):
+    """tests/conftest.py::oracle_time_budget: a heavy CPU-oracle test skips (with the reason) only when starting it would eat
+    into the reserve of the 900 s GPU session; the clock is shared by both import names of conftest."""
+    import time
+    import pytest
+    from tests import conftest as C
+    monkeypatch.setattr(C, "_SESSION_T0", time.time() - 100.0)
+    C.oracle_time_budget(130)                                    # 230 s < 600 s: runs
+    monkeypatch.setattr(C, "_SESSION_T0", time.time() - 500.0)
+    C.oracle_time_budget(45)                                     # 545 s < 600 s: runs
+    with pytest.raises(pytest.skip.Exception, match="time budget of the GPU session"):
+        C.oracle_time_budget(130)                                # 630 s > 600 s: skips
+    assert float(os.environ["MVD_GPU_SUITE_T0"]) <= time.time()
