@@ -85,3 +85,40 @@ def test_prepare_latents_generator_list_follows_diffusers_randn_tensor():
     # caller-provided latents are only scaled (prepare_latents' latents= branch)
     lat = torch.ones(1, 4, 8, 6)
     assert torch.equal(pipe.prepare_latents(1, 4, 64, 48, torch.float32, torch.device("cpu"), None, latents=lat), 2.0 * lat)
+
+
+def test_ddpm_step_is_the_gaussian_posterior_from_first_principles():
+    """``oracle.scheduler.ddpm_step`` restates diffusers' ``DDPMScheduler.step`` (pipeline.py:161; diffusers is absent, so there is
+    no fixture of it).  What CAN pin it is the published algorithm itself (Ho et al. 2020, eq. 6-7; v-prediction: Salimans & Ho
+    2022): with x_t = sqrt(a_t) x0 + sqrt(1 - a_t) eps and the TRUE eps / v as the model output, the step must (i) recover x0
+    exactly and (ii) return the mean of the Gaussian posterior q(x_{t-k} | x_t, x0), derived here independently by conditioning
+    x_{t-k} ~ N(sqrt(a_prev) x0, (1 - a_prev) I), x_t | x_{t-k} ~ N(sqrt(a_t / a_prev) x_{t-k}, (1 - a_t / a_prev) I) (precision-
+    weighted form, no shared algebra with the restatement), and (iii) add noise with exactly the posterior's variance ("fixed_small");
+    the last step (t - k < 0 -> a_prev = 1) returns x0 itself.  fp64, strided schedule as ``set_timesteps`` makes it."""
+    betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float64) ** 2          # SD's scaled-linear betas
+    acp = torch.cumprod(1.0 - betas, 0)
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.randn(2, 4, 8, 8, generator=g, dtype=torch.float64)
+    eps = torch.randn(2, 4, 8, 8, generator=g, dtype=torch.float64)
+    nz = torch.randn(2, 4, 8, 8, generator=g, dtype=torch.float64)
+    for n_steps in (20, 50, 1000):
+        k = 1000 // n_steps
+        for t in (999 // k * k if n_steps < 1000 else 999, 500 // k * k, k, 0):
+            a_t = acp[t]
+            a_prev = acp[t - k] if t - k >= 0 else torch.tensor(1.0, dtype=torch.float64)
+            x_t = a_t.sqrt() * x0 + (1 - a_t).sqrt() * eps
+            v = a_t.sqrt() * eps - (1 - a_t).sqrt() * x0
+            # the posterior by Gaussian conditioning (precisions add, means are precision-weighted)
+            a_step = a_t / a_prev
+            if t - k >= 0:
+                prec_prior, prec_like = 1.0 / (1 - a_prev), a_step / (1 - a_step)
+                var_post = 1.0 / (prec_prior + prec_like)
+                mean_post = var_post * (prec_prior * a_prev.sqrt() * x0 + prec_like * x_t / a_step.sqrt())
+            else:                                        # a_prev = 1: x_{t-k} IS x0
+                var_post, mean_post = torch.tensor(0.0, dtype=torch.float64), x0
+            for kind, out in (("epsilon", eps), ("v_prediction", v)):
+                mean = OS.ddpm_step(out, t, x_t, acp, 1000, n_steps, kind, torch.zeros_like(nz))
+                assert torch.allclose(mean, mean_post, rtol=0, atol=1e-11), (n_steps, t, kind, (mean - mean_post).abs().max())
+                noisy = OS.ddpm_step(out, t, x_t, acp, 1000, n_steps, kind, nz)
+                want_std = var_post.clamp_min(1e-20).sqrt() if t > 0 else torch.tensor(0.0, dtype=torch.float64)
+                assert torch.allclose(noisy - mean, want_std * nz, rtol=0, atol=1e-11), (n_steps, t, kind)
