@@ -85,3 +85,36 @@ def test_multiview_cfg_batch_mismatch_q4():
                                  None, None, lat)
     assert y.shape == (2, 4, 16, 16) and torch.isfinite(y).all()
     assert not torch.allclose(y[0], y[1])   # rows see different halves of the reference tokens
+
+
+def test_oracle_attention_equals_torch_multihead_attention():
+    """An implementation the repo did not write: ``torch.nn.MultiheadAttention`` (Vaswani et al. multi-head attention, separate
+    q / k / v projections because the text width differs from the channel width) loaded with the same weights must reproduce
+    ``oracle.sd21_unet.attention`` -- the contiguous-by-head channel split, the 1/sqrt(d) scale and the biased out-projection of
+    diffusers' ``Attention`` + ``AttnProcessor2_0`` (SURVEY 8a layer table) -- for self-attention (ctx = h) and text cross-attention."""
+    import torch
+    from oracle import sd21_unet as OU
+    g = torch.Generator().manual_seed(5)
+    for C, heads, xdim, n_ctx in ((320, 5, 320, None), (640, 10, 1024, 77), (128, 2, 96, 7)):
+        key = "blk.attn"
+        p = {f"{key}.to_q.weight": torch.randn(C, C, generator=g) / C ** 0.5,
+             f"{key}.to_k.weight": torch.randn(C, xdim, generator=g) / xdim ** 0.5,
+             f"{key}.to_v.weight": torch.randn(C, xdim, generator=g) / xdim ** 0.5,
+             f"{key}.to_out.0.weight": torch.randn(C, C, generator=g) / C ** 0.5,
+             f"{key}.to_out.0.bias": torch.randn(C, generator=g)}
+        h = torch.randn(2, 48, C, generator=g)
+        ctx = h if n_ctx is None else torch.randn(2, n_ctx, xdim, generator=g)
+        mha = torch.nn.MultiheadAttention(C, heads, bias=True, kdim=xdim, vdim=xdim, batch_first=True)
+        with torch.no_grad():
+            if xdim == C:                                   # same widths: torch keeps one stacked in-projection
+                mha.in_proj_weight.copy_(torch.cat([p[f"{key}.to_q.weight"], p[f"{key}.to_k.weight"], p[f"{key}.to_v.weight"]], 0))
+            else:
+                mha.q_proj_weight.copy_(p[f"{key}.to_q.weight"])
+                mha.k_proj_weight.copy_(p[f"{key}.to_k.weight"])
+                mha.v_proj_weight.copy_(p[f"{key}.to_v.weight"])
+            mha.in_proj_bias.zero_()                        # to_q / to_k / to_v carry no bias
+            mha.out_proj.weight.copy_(p[f"{key}.to_out.0.weight"])
+            mha.out_proj.bias.copy_(p[f"{key}.to_out.0.bias"])
+            want, _ = mha(h, ctx, ctx, need_weights=False)
+            got = OU.attention(p, key, h, ctx, heads)
+        assert torch.allclose(got, want, rtol=1e-4, atol=1e-5), (C, heads, (got - want).abs().max().item())
