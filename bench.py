@@ -140,16 +140,20 @@ def make_batch(pairs: int, rank: int, device, lat_hw: int = 64):
 
 def cpu_baseline(timed_runs: int = 3, warmup_runs: int = 1, latent: int = 64):
     """The oracle (CPU fp32 restatement, oracle/mvd.py) timed on this box's host cores: configs[2] (B=1, adapter + camera
-    on, cold forward; ~13 s per forward on the GPU box's 128 usable threads).  BASELINE.md section 3 protocol: 1 warm-up
-    forward, then ``timed_runs`` timed ones, MEDIAN reported (~55 s of CPU work in all).  The only place bench.py
+    on, cold forward; 13-16 s per forward with torch's default 128 threads on the GPU box, whose cgroup grants 16 cores -- hence
+    ``oracle.host_threads()``).  BASELINE.md section 3 protocol: 1 warm-up forward, then ``timed_runs`` timed ones, MEDIAN reported.  The only place bench.py
     touches ``oracle/`` (and tests/parity_util, which imports it)."""
     import statistics
     from oracle import mvd as OM
     from oracle import sd21_unet as OU
     from tests.parity_util import make_inputs
-    # torch's default intra-op thread count (the box's usable cores); os.cpu_count() reports all 256 host
-    # threads of the node and over-subscribing them makes the forward 30x slower
-    cores = torch.get_num_threads()
+    # the threads the box can actually run: torch's default capped by the cgroup CPU quota (16 cores on the pool's one-GPU boxes,
+    # where os.cpu_count() and the affinity mask show all 256 hardware threads and torch defaults to 128 -- 128 threads on a
+    # 16-core quota run this forward 3.9x slower than 16 do, profiles/r04_probe_oracle_threads.log)
+    import oracle
+    default_threads = torch.get_num_threads()
+    cores = oracle.host_threads()
+    torch.set_num_threads(cores)
     cfg = OU.UNetConfig.sd21()
     params = OM.init_mvd_params(cfg, 0, share_encoder=True)
     inp = make_inputs(cfg, 1, latent, 77, 0, 1024)
@@ -162,11 +166,13 @@ def cpu_baseline(timed_runs: int = 3, warmup_runs: int = 1, latent: int = 64):
             if i >= warmup_runs:
                 times.append(time.perf_counter() - t0)
     med = statistics.median(times)
+    torch.set_num_threads(default_threads)
     return {"value": 1.0 / med, "unit": "forward-passes/s", "cores": cores, "kind": "port",
             "sample": f"oracle/mvd.py, configs[2] (B=1, {latent}x{latent} latent, adapter+camera on, cold forward = "
                       f"{(unet_flops(latent, latent, adapter=True) + unet_flops(latent, latent)) / 1e9:.0f} GFLOP), "
                       f"{warmup_runs} warm-up + {timed_runs} timed forwards (median; min {min(times):.2f} s, max {max(times):.2f} s), "
-                      f"torch fp32 on {cores} host threads (os.cpu_count()={os.cpu_count()}), {med:.2f} s/forward"}
+                      f"torch fp32 on {cores} host threads (torch default {default_threads}, os.cpu_count()={os.cpu_count()}; "
+                      f"capped by the cgroup CPU quota), {med:.2f} s/forward"}
 
 
 def _strip_comments(src: str) -> str:

@@ -27,3 +27,40 @@ Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
 leg may import this package, and only as the checker.  The product path
 (``mvd_amd``) never imports it and has no CPU fallback.
 """
+import math as _math
+import os as _os
+
+
+def host_threads(default: int = 0) -> int:
+    """Intra-op threads the CPU oracle should run with: torch's default (physical cores), capped by the affinity mask AND by the
+    cgroup CPU quota.  The pool's one-GPU boxes show 256 hardware threads (``os.cpu_count()``, the affinity mask) and torch
+    defaults to 128 threads, but the cgroup grants 16 cores of CPU time (``cpu.max`` = "1600000 100000"): 128 runnable threads on
+    a 16-core quota are throttled in bursts and the oracle's fp32 forward runs 3.9x SLOWER than with 16 threads (3.3 s vs 0.83 s
+    per base-UNet forward at 32 x 32, profiles/r04_probe_oracle_threads.log)."""
+    n = int(default) if default else 0
+    if n <= 0:
+        try:
+            import torch
+            n = torch.get_num_threads()
+        except Exception:          # pragma: no cover
+            n = _os.cpu_count() or 1
+    try:
+        n = min(n, len(_os.sched_getaffinity(0)))
+    except (AttributeError, OSError):     # pragma: no cover
+        pass
+    quota = None
+    try:                                   # cgroup v2
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(p)
+    except (OSError, ValueError):
+        try:                               # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                quota = q / p
+        except (OSError, ValueError):
+            pass
+    if quota:
+        n = min(n, max(1, _math.ceil(quota)))
+    return max(1, n)

@@ -13,6 +13,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _oracle_host_threads():
+    """The CPU oracle (and every other host-side torch op of the tests) runs with the threads the box can actually schedule:
+    torch's default capped by the cgroup CPU quota (oracle.host_threads: 16 on the pool's GPU boxes, where torch defaults to 128
+    and the oracle then runs 3.9x slower)."""
+    import torch
+    import oracle
+    before = torch.get_num_threads()
+    torch.set_num_threads(oracle.host_threads())
+    yield
+    torch.set_num_threads(before)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")

@@ -214,3 +214,36 @@ def test_gpu_session_time_budget_guard(monkeypatch):
     with pytest.raises(pytest.skip.Exception, match="time budget of the GPU session"):
         C.oracle_time_budget(130)                                # 630 s > 600 s: skips
     assert float(os.environ["MVD_GPU_SUITE_T0"]) <= time.time()
+
+
+def test_oracle_host_threads_respects_the_cgroup_quota(monkeypatch):
+    """oracle.host_threads: torch's default, capped by the affinity mask and by the cgroup CPU quota (cpu.max "1600000 100000" =
+    16 cores on the GPU boxes, where torch defaults to 128 threads and the oracle then runs 3.9x slower)."""
+    import builtins
+    import io
+    import oracle
+    real_open = builtins.open
+
+    def fake(content):
+        def _open(path, *a, **k):
+            if str(path) == "/sys/fs/cgroup/cpu.max":
+                if content is None:
+                    raise FileNotFoundError(path)
+                return io.StringIO(content)
+            if str(path).startswith("/sys/fs/cgroup/cpu/"):
+                raise FileNotFoundError(path)
+            return real_open(path, *a, **k)
+        return _open
+
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(256)))
+    monkeypatch.setattr(builtins, "open", fake("1600000 100000\n"))
+    assert oracle.host_threads(128) == 16
+    assert oracle.host_threads(8) == 8                      # fewer threads than the quota: unchanged
+    monkeypatch.setattr(builtins, "open", fake("250000 100000\n"))
+    assert oracle.host_threads(128) == 3                    # 2.5 cores -> 3 threads
+    monkeypatch.setattr(builtins, "open", fake("max 100000\n"))
+    assert oracle.host_threads(128) == 128                  # no quota
+    monkeypatch.setattr(builtins, "open", fake(None))
+    assert oracle.host_threads(128) == 128                  # no cgroup file at all
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(12)))
+    assert oracle.host_threads(128) == 12                   # the affinity mask caps as well
