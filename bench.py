@@ -320,6 +320,12 @@ def e2e_workload(args, dev):
     return 0
 
 
+# Many-image shards (BASELINE configs[3] / [4]: 32 pairs per GPU) never read the batch-1 twins of the packed weights (the `.ws`
+# convolution streams and the C > 640 LayerNorm-folded copies: launches with M <= 1024 rows, or <= 12 GFLOP up to M = 4608): they
+# are packed lean, which is also what the start-up broadcast then moves (3.7 GB per rank instead of 6.5 GB).
+LEAN_PACKING_FROM_PAIRS = 16
+
+
 def launch_dry_run(args, D):
     """The N > 1 control flow of main() with the GPU work left out (CPU test of the self-launching entry): gloo process
     group from the launcher's environment, a weight-arena broadcast through the product's own helper, the barriers and the
@@ -434,7 +440,8 @@ def main():
     # (dedup_encoder_weights=False: the synthetic image-encoder weights differ from the base UNet's, as a trained checkpoint's
     #  do -- and the all-zero placeholders of ranks > 0 must not be "de-duplicated" into a different arena layout than rank 0's)
     model = MultiViewUNet(None, unet_config=UNetConfig.sd21(), init="empty", img_ref_scale=0.3,
-                          cam_modulation_strength=0.2, cache_reference=args.cached, dedup_encoder_weights=False).to(dev)
+                          cam_modulation_strength=0.2, cache_reference=args.cached, dedup_encoder_weights=False,
+                          small_batch_twins=pairs < LEAN_PACKING_FROM_PAIRS).to(dev)
     model.eval()
     model.use_hip_graph = args.graph
     if args.global_ref_stats:

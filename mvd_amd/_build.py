@@ -11,13 +11,17 @@ SOURCES = ["gemm.hip", "gemm_pp.hip", "gemm_sm.hip", "gemm_xs.hip", "conv_ws.hip
 # measurement-only experiment kernels: linked by tools/build_variant.py into probe builds (-DMVD_PROBE), never into the product
 PROBE_SOURCES = ["probe/gemm_ring.hip"]     # (+ probe/attention_probe*.inc, included by attention.hip under -DMVD_PROBE)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-# -packed-fp32-ops (device code generation without v_pk_{fma,mul,add}_f32): round 4 traced the run-to-run differences of the
-# reverted four-pixel conv_out on a GPU shared by two processes to hipcc's SLP-vectorised `v_pk_fma_f32 ... op_sel:[0,1,0]`
-# (low result half taking the HIGH register of a source pair); the same source with scalar v_fma_f32, or with exactly those 38
-# instructions rewritten in the assembly, is stable (profiles/r04_probe_conv_out4_diagnosis.log).  The product's
-# kernels held ~350 instructions of that class, so packed fp32 selection is off for the whole library: same IEEE operations per
-# element (outputs bit-identical), 0-0.3 % of a step.  The host pass prints "not a recognized feature" for it and ignores it.
+# -packed-fp32-ops (device code generation without v_pk_{fma,mul,add}_f32): a PRECAUTION against an unexplained fault.  The
+# four-pixel conv_out probe kernel (csrc/probe/conv_out4.inc, not shipped) gave run-to-run differences when two processes shared
+# one GPU; the differences went away with scalar v_fma_f32 and when exactly its 38 `v_pk_fma_f32 ... op_sel:[0,1,0]` were
+# rewritten in the assembly (profiles/r04_probe_conv_out4_diagnosis.log).  That localises the fault to an
+# instruction form; the root cause is NOT known (a wave context save/restore or time-slicing problem that the changed register
+# allocation merely hides fits the same evidence).  The product is built without that instruction class: same IEEE operation per
+# element (outputs bit-identical), 0-0.3 % of a step.  The flag reaches both passes: hipcc 7.2 refuses to forward -Xclang through
+# -Xarch_device and silently ignores `-Xarch_device -mno-packed-fp32-ops` (checked: the packed instruction is still selected), so
+# the host pass's "'-packed-fp32-ops' is not a recognized feature" note is dropped from the build output below instead.
 NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+HOST_PASS_NOISE = "'-packed-fp32-ops' is not a recognized feature for this target"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", *NO_PACKED_FP32]
 
 
@@ -45,7 +49,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
-        return r.stderr
+        return "\n".join(ln for ln in r.stderr.splitlines() if HOST_PASS_NOISE not in ln)
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         for warn in ex.map(run, jobs):

@@ -63,6 +63,21 @@ class UNetConfig:
             prev_out = oc
         return out
 
+    def resnet_input_split(self):
+        """{diffusers key: (c0, c1)}: the two source tensors of a resnet's input -- up-block resnets read cat([hidden, skip]) (the
+        engine never materialises it: GroupNorm and the 1x1 shortcut read both sources), every other resnet has c1 = 0."""
+        out = {}
+        n = self.num_levels
+        rev = list(reversed(self.block_out_channels))
+        for key, cin, _cout in self.resnets():
+            if key.startswith("up_blocks."):
+                i, j = int(key.split(".")[1]), int(key.split(".")[3])
+                skip = rev[min(i + 1, n - 1)] if j == self.layers_per_block else rev[i]
+                out[key] = (cin - skip, skip)
+            else:
+                out[key] = (cin, 0)
+        return out
+
     def transformers(self):
         """[(diffusers key, feature name, channels, heads)] in module order (= ImageEncoder hook order)."""
         out = []

@@ -114,7 +114,10 @@ MVD_DEVINL void ws_pass(const __amdgpu_buffer_rsrc_t rs_x, const unsigned (&svo)
       // another stream's kernel have delayed in the LDS queue: one k-chunk of the tile multiplies the wrong weights.  Seen only
       // in the two-stream forward, in the one-tap (fused shortcut) passes, where read and refill sit in the same step
       // (profiles/r04_probe_conv_ws_in_situ.log).
-      asm volatile("" ::"v"(__builtin_bit_cast(u32x4, wf)) : "memory");
+      // The comment travels into the compiler's assembly output: tools/lint_device_isa.py (--conv-ws-fences, run by
+      // __graft_entry__.build() and a CPU test) finds the ds_read that filled the named registers and fails unless an
+      // `s_waitcnt lgkmcnt` that retires it stands between that read and this fence.
+      asm volatile("; MVD_REFILL_FENCE %0" ::"v"(__builtin_bit_cast(u32x4, wf)) : "memory");
       if constexpr (LA == 2) issue_w(rd + 2, t, half + t);
       if (t + 1 < T) {
         wf = wn;

@@ -531,15 +531,20 @@ int launch_mode(const MvdGemmArgs& a, hipStream_t s) {
   return launch_mode2<C, AMODE, GLDS, false>(a, s);
 }
 
-template <class C>
+// DMA_ONLY: the tile exists with LDS-DMA staging only (the 256x320 tile: its register-staged form spills 37-43 VGPRs to scratch
+// memory and was never reachable in the product -- tools/lint_device_isa.py fails the build on any shipped kernel with scratch)
+template <class C, bool DMA_ONLY = false>
 int launch_cfg(const MvdGemmArgs& a, hipStream_t s, bool glds) {
   if (a.splitk > 1) glds = true;   // split-K exists for the LDS-DMA variants only
-  if (glds) {
+  if (glds || DMA_ONLY) {
     if (a.seg[0].mode == MVD_A_DENSE) return launch_mode<C, 0, true>(a, s);
     return a.nseg == 1 ? launch_mode<C, 1, true>(a, s) : launch_mode<C, 2, true>(a, s);
   }
-  if (a.seg[0].mode == MVD_A_DENSE) return launch_mode<C, 0, false>(a, s);
-  return a.nseg == 1 ? launch_mode<C, 1, false>(a, s) : launch_mode<C, 2, false>(a, s);
+  if constexpr (!DMA_ONLY) {
+    if (a.seg[0].mode == MVD_A_DENSE) return launch_mode<C, 0, false>(a, s);
+    return a.nseg == 1 ? launch_mode<C, 1, false>(a, s) : launch_mode<C, 2, false>(a, s);
+  }
+  return -1;
 }
 
 using C0 = Cfg<256, 160, 4, 2>;
@@ -697,7 +702,7 @@ int mvd_launch_gemm(const MvdGemmArgs& a, hipStream_t s, int force_cfg) {
 #ifdef MVD_PROBE
       if (use_ring && !a.out_f32 && !a.dbg) return mvd_launch_gemm_ring(a, s);
 #endif
-      return launch_cfg<C7>(a, s, true);
+      return launch_cfg<C7, true>(a, s, true);
     default: return launch_cfg<C5>(a, s, glds);
   }
 }

@@ -5,6 +5,7 @@ data flow (replica-local Q2 statistics)."""
 from __future__ import annotations
 
 import os
+import socket
 import time
 from typing import Dict, Iterable, List, Sequence
 
@@ -253,7 +254,7 @@ def collective_library() -> str:
 def device_identity(local_rank: int) -> Dict[str, object]:
     """What distinguishes this rank's GPU from the others' on one node: LOCAL_RANK, the device index it bound, and the
     device's UUID / PCI bus id where the runtime exposes them (a CPU-only rehearsal reports the process id instead)."""
-    ident: Dict[str, object] = {"local_rank": int(local_rank), "pid": os.getpid()}
+    ident: Dict[str, object] = {"local_rank": int(local_rank), "pid": os.getpid(), "host": socket.gethostname()}
     if torch.cuda.is_available():
         idx = torch.cuda.current_device()
         ident["device"] = idx
@@ -279,16 +280,32 @@ def gather_identities(local_rank: int) -> List[Dict[str, object]]:
     return out       # type: ignore[return-value]
 
 
+def _usable_uuid(u) -> bool:
+    """A UUID the runtime really reported: not missing, not a placeholder, not all zeros."""
+    s = str(u if u is not None else "").strip().lower()
+    if s in ("", "none", "?", "n/a"):
+        return False
+    body = s[4:] if s.startswith("gpu-") else s
+    return any(c not in "0-: " for c in body)
+
+
 def distinct_devices(idents: Sequence[Dict[str, object]]) -> int:
-    """Number of different GPUs among the gathered identities: two ranks share a GPU only if EVERYTHING the runtime reports
-    about their devices agrees (UUID, PCI bus / device id, bound device index) -- a runtime that hands every device the same
-    UUID must not make eight GPUs count as one.  Without a GPU (CPU rehearsal) the process id stands in."""
+    """Number of different GPUs among the gathered identities.  A GPU is (host, UUID) when the runtime reports usable UUIDs
+    that are not all the same -- two ranks that reach one physical GPU through different visibility masks / device indices
+    then count ONCE, and equal tuples on different hosts count twice.  Where UUIDs are absent or degenerate (every device the
+    same one) the key falls back to (host, PCI bus id, PCI device id, bound device index), so a runtime that hands every
+    device the same UUID cannot make eight GPUs count as one.  Without a GPU (CPU rehearsal) host + process id stand in."""
+    gpu = [d for d in idents if "device" in d]
+    uuids = [str(d.get("uuid")) for d in gpu]
+    by_uuid = bool(gpu) and all(_usable_uuid(u) for u in uuids) and (len(gpu) == 1 or len(set(uuids)) > 1)
     keys = []
     for d in idents:
-        if "device" in d:
-            keys.append(("gpu", d.get("uuid"), d.get("pci_bus_id"), d.get("pci_device_id"), d.get("device")))
+        if "device" not in d:
+            keys.append(("pid", d.get("host"), d.get("pid")))
+        elif by_uuid:
+            keys.append(("gpu", d.get("host"), str(d.get("uuid"))))
         else:
-            keys.append(("pid", d.get("pid")))
+            keys.append(("gpu", d.get("host"), d.get("pci_bus_id"), d.get("pci_device_id"), d.get("device")))
     return len(set(keys))
 
 

@@ -122,7 +122,8 @@ class MultiViewUNet(nn.Module):
                  img_ref_scale: float = 0.3, cam_modulation_strength: float = 0.2, cam_output_dim: int = 1024,
                  cam_hidden_dim: int = 512, use_camera_conditioning: bool = True, use_image_conditioning: bool = True,
                  simple_cam_encoder: bool = False, *, unet_config: Optional[UNetConfig] = None, init: str = "default",
-                 cache_reference: bool = False, dedup_encoder_weights="auto", cache_dir=None):
+                 cache_reference: bool = False, dedup_encoder_weights="auto", cache_dir=None,
+                 small_batch_twins: Optional[bool] = None):
         super().__init__()
         self.use_camera_conditioning = use_camera_conditioning
         self.use_image_conditioning = use_image_conditioning
@@ -137,6 +138,10 @@ class MultiViewUNet(nn.Module):
         # "auto" compares the two state dicts when the engine packs them and keeps ONE packed copy if they are equal
         self.dedup_encoder_weights = dedup_encoder_weights
         self.encoder_weights_shared = False
+        # the second packed copies only a batch-1 forward reads (packing.pack_unet: ~0.7 GB per weight set).  None: the engine's
+        # default (on unless MVD_PACK_SMALL_BATCH_TWINS=0); False for a deployment that only runs many-image batches -- the
+        # data-parallel shards of BASELINE configs[3] / [4] then pack, hold and BROADCAST 3.7 GB instead of 6.5 GB
+        self.small_batch_twins = small_batch_twins
 
         # mvd_unet.py:46-52: UNet2DConditionModel.from_pretrained(name, subfolder="unet").  Here: a snapshot directory or a
         # hub name already in a local huggingface cache (hub.resolve_snapshot); a name nothing local answers to RAISES
@@ -230,7 +235,7 @@ class MultiViewUNet(nn.Module):
         dev = self._exec_device()
         if self._engine is None or self._engine.device != dev:
             self._engine = MVDEngine(self.unet_config, self.cam_output_dim, self.cam_hidden_dim, self.simple_cam_encoder,
-                                     self.cam_modulation_strength, device=dev)
+                                     self.cam_modulation_strength, device=dev, small_batch_twins=self.small_batch_twins)
             self._dirty = True
         if self._dirty:
             sd = self.base_unet.state_dict()

@@ -152,6 +152,13 @@ def fold_layernorm(w: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, bia
     return wf.to(device).contiguous(), torch.stack([c1, c2], 0).to(device=device, dtype=torch.float32).contiguous()
 
 
+def ws_twin_shapes_ok(c: int, n: int, scc0: int, scc1: int) -> bool:
+    """The channel rules of conv_ws.hip ``mvd_conv_ws_applicable``: input width a multiple of 128 (a round), output width a multiple
+    of 16 (a column tile), and EACH source of a fused 1x1 shortcut a multiple of 128 on its own (the halves of a skip
+    concatenation are separate tensors)."""
+    return c > 0 and c % 128 == 0 and n > 0 and n % 16 == 0 and scc0 % 128 == 0 and scc1 % 128 == 0 and not (scc1 and not scc0)
+
+
 def pack_unet(sd: Dict[str, torch.Tensor], cfg: UNetConfig, device, adapter: bool, ref_scale: float = 0.0,
               small_batch_twins: bool = True) -> Dict[str, torch.Tensor]:
     """``sd`` holds diffusers keys (no wrapper prefix) and, when ``adapter``, the ``...processor.*`` keys.
@@ -170,6 +177,7 @@ def pack_unet(sd: Dict[str, torch.Tensor], cfg: UNetConfig, device, adapter: boo
     out["time.l2.w"] = _bf(sd["time_embedding.linear_2.weight"], device)
     out["time.l2.b"] = _f32(sd["time_embedding.linear_2.bias"], device)
     tw, tb = [], []
+    split = cfg.resnet_input_split()
     for key, cin, cout in cfg.resnets():
         out[f"{key}.norm1.g"] = _f32(sd[f"{key}.norm1.weight"], device)
         out[f"{key}.norm1.b"] = _f32(sd[f"{key}.norm1.bias"], device)
@@ -185,13 +193,15 @@ def pack_unet(sd: Dict[str, torch.Tensor], cfg: UNetConfig, device, adapter: boo
         out[f"{key}.conv2.w"] = _bf(w2, device)
         out[f"{key}.conv2.b"] = _f32(b2, device)
         # weight-streaming twins (conv_ws.hip) for every level but the first -- the 32x32, 16x16 and 8x8 maps of a 64x64 latent,
-        # where a batch-1 launch is a weight stream (input / output widths the kernel takes: % 128 and % 16)
-        if small_batch_twins and cout > cfg.block_out_channels[0] and cout % 128 == 0:
-            if cin % 128 == 0:
+        # where a batch-1 launch is a weight stream -- and only where the kernel's shape predicate can ever say yes
+        # (ws_twin_shapes_ok = mvd_conv_ws_applicable's channel rules: a twin nothing can read is not packed, nor broadcast)
+        if small_batch_twins and cout > cfg.block_out_channels[0]:
+            if ws_twin_shapes_ok(cin, cout, 0, 0):
                 out[f"{key}.conv1.ws"] = pack_ws(sd[f"{key}.conv1.weight"], None, device)
             if cin == cout:
-                out[f"{key}.conv2.ws"] = pack_ws(sd[f"{key}.conv2.weight"], None, device)
-            elif cin % 128 == 0:
+                if ws_twin_shapes_ok(cout, cout, 0, 0):
+                    out[f"{key}.conv2.ws"] = pack_ws(sd[f"{key}.conv2.weight"], None, device)
+            elif ws_twin_shapes_ok(cout, cout, *split[key]):
                 out[f"{key}.conv2.ws"] = pack_ws(sd[f"{key}.conv2.weight"], sd[f"{key}.conv_shortcut.weight"].reshape(cout, cin), device)
         tw.append(sd[f"{key}.time_emb_proj.weight"].detach().float())
         tb.append(sd[f"{key}.time_emb_proj.bias"].detach().float())

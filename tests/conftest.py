@@ -31,26 +31,53 @@ def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
 
 
-# ---- time budget of the -m gpu session.  The driver gives the GPU suite 900 s.  The suite is bound by the CPU ORACLE, not by
-# the GPU: of 371 s on a typical box (profiles/r04_gputests_durations.txt) 140 s are the fp32 restatement of the 32-pair
-# forward, 42 + 16 s the 50- / 20-step drift loops, 41 s the full-size CFG loop, 14 s the 768 x 768 forward -- and a box whose
-# host cores were busy ran the same suite in 642 s (profiles/r04_gputests_final_head.txt), 1.7x slower.  A heavy oracle test
-# asks here before it starts (with its cost on the typical box): if running it would leave less than the reserve for the tests
-# behind it, it SKIPS with the reason spelled out instead of letting the whole session be killed at the limit.  Nothing is
-# skipped on either of the two boxes above (the last guarded test starts at ~250 s / ~490 s against a threshold of 600 s).
-import time as _time
+# ---- the headline parity tests cannot drop out of a green record (round-4 verdict, item 2).  Round 4 had a time-budget guard here
+# that let the heaviest CPU-oracle tests skip themselves on a slow box; with oracle.host_threads() the oracle legs cost a quarter
+# of what they did, so the guard is gone, and a `-m gpu` session that selected the tests carrying BASELINE configs[1..3] (and
+# infer.py's own defaults) FAILS unless every one of them ran and passed -- a skip or a deselection inside the session counts as
+# a failure.
+MUST_PASS_ON_GPU = (
+    "tests/test_engine_gpu.py::test_sd21_full_size_parity_base_unet_only",      # configs[1]: base UNet, B = 1
+    "tests/test_engine_gpu.py::test_sd21_full_size_parity",                     # configs[2]: 1 -> 1 view, adapter + camera
+    "tests/test_cfg4_shapes_gpu.py::test_sd21_full_size_parity_b32",            # configs[3]: 32 pairs
+    "tests/test_engine_gpu.py::test_sd21_full_size_parity_768",                 # the reference's default image size
+    "tests/test_engine_gpu.py::test_sd21_full_size_denoise_loop_cfg",           # chained forwards under CFG (Q4)
+    "tests/test_engine_gpu.py::test_sd21_full_size_infer_defaults_loop",        # infer.py:181-187: 20 steps, guidance 1.0, B = 1
+)
+_OUTCOMES = {}
 
-# (the start time lives in the environment of this process: pytest may load this file as `conftest` while the tests import it
-#  as `tests.conftest` -- two module objects, one clock)
-_SESSION_T0 = float(os.environ.setdefault("MVD_GPU_SUITE_T0", repr(_time.time())))
-GPU_SUITE_LIMIT_S = float(os.environ.get("MVD_GPU_SUITE_LIMIT_S", "900"))
-GPU_SUITE_RESERVE_S = float(os.environ.get("MVD_GPU_SUITE_RESERVE_S", "300"))     # what runs after the heavy tests, on a slow box
+
+def pytest_runtest_logreport(report):
+    if report.nodeid not in MUST_PASS_ON_GPU:
+        return
+    if report.outcome != "passed":                       # a skip or a failure in any phase sticks
+        _OUTCOMES[report.nodeid] = report.outcome
+    elif report.when == "call":
+        _OUTCOMES.setdefault(report.nodeid, "passed")
 
 
-def oracle_time_budget(nominal_cost_s: float):
-    """Call at the top of a test whose CPU-oracle leg costs ~``nominal_cost_s`` on a typical box."""
-    elapsed = _time.time() - _SESSION_T0
-    if elapsed + nominal_cost_s > GPU_SUITE_LIMIT_S - GPU_SUITE_RESERVE_S:
-        pytest.skip(f"time budget of the GPU session: {elapsed:.0f} s used, this test's CPU oracle needs ~{nominal_cost_s:.0f} s, "
-                    f"{GPU_SUITE_RESERVE_S:.0f} s are reserved for the tests behind it (limit {GPU_SUITE_LIMIT_S:.0f} s; "
-                    "MVD_GPU_SUITE_LIMIT_S=1e9 runs everything)")
+def missing_headline_tests(collected_ids, outcomes, have_gpu: bool):
+    """The headline tests of a session that did not pass.  Enforced only for a session that has a GPU and collected ALL of them
+    (the driver's `pytest tests -m gpu`); a run of one file or one -k expression is not held to it."""
+    if not have_gpu or not all(t in collected_ids for t in MUST_PASS_ON_GPU):
+        return []
+    return [f"{t}: {outcomes.get(t, 'did not run')}" for t in MUST_PASS_ON_GPU if outcomes.get(t) != "passed"]
+
+
+def pytest_collection_modifyitems(session, config, items):
+    session.config._mvd_selected = {it.nodeid for it in items}
+
+
+def pytest_sessionfinish(session, exitstatus):
+    import torch
+    sel = getattr(session.config, "_mvd_selected", set())
+    if getattr(session, "shouldstop", False) or getattr(session, "shouldfail", False):
+        return                                   # -x stopped the session at an earlier failure: that failure is the verdict
+    bad = missing_headline_tests(sel, _OUTCOMES, torch.cuda.is_available())
+    if bad:
+        tr = session.config.pluginmanager.get_plugin("terminalreporter")
+        msg = "headline parity tests that did not pass in this GPU session:\n  " + "\n  ".join(bad)
+        if tr is not None:
+            tr.write_sep("=", "MVD: configs[1..3] parity is not optional", red=True)
+            tr.write_line(msg)
+        session.exitstatus = 1

@@ -314,8 +314,6 @@ def test_sd21_full_size_parity_768():
     """The reference's own default: 768 x 768 images = 96 x 96 latents (infer.py:187, config/train_config.yaml sample_size 96), full
     SD-2.1 shapes, B = 1, camera FiLM + cross-view adapter, cold forward: 9216 tokens at the first level (the split-KV attention,
     the small-M GEMMs at M = 9216 / 2304 / 576 / 144) under the checker.  The oracle needs ~40 s of CPU."""
-    from tests.conftest import oracle_time_budget
-    oracle_time_budget(15)
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from tests.parity_util import run_tiny_parity
@@ -330,8 +328,6 @@ def test_sd21_full_size_denoise_loop_cfg():
     per forward under CFG: the Q4 re-chunking of the reference tokens), camera + image conditioning, the per-step Fourier
     projection pinned, the same ancestral noise draws as ``oracle/scheduler.denoise_loop``.  Quantifies the error growth over
     chained bf16 forwards (one forward: rel-L2 ~1e-2): stated tolerance rel-L2 <= 5e-2 on the final latents."""
-    from tests.conftest import oracle_time_budget
-    oracle_time_budget(45)
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from mvd_amd.pipeline import MVDDenoiser
@@ -357,3 +353,45 @@ def test_sd21_full_size_denoise_loop_cfg():
     print("full-size 4-step CFG loop rel-L2", err, flush=True)
     assert torch.isfinite(got).all()
     assert err <= 5e-2, err
+
+
+def test_sd21_full_size_infer_defaults_loop():
+    """The reference's own driver settings under the checker (round-4 verdict, item 2): ``infer.py:181-187`` runs B = 1, **20 steps,
+    guidance scale 1.0** (no CFG: one latent per forward), camera + image conditioning, the reference encoder re-run every step
+    (the reference-faithful cold forward, Q5 off) -- here at full SD-2.1 size on 64 x 64 latents (BASELINE's 512 x 512), Q1's
+    projection pinned per step, the oracle's ancestral noise draws (the trajectories differ by arithmetic only), against
+    ``oracle/scheduler.denoise_loop`` (pipeline.py:140-166).  Checked on the WHOLE trajectory.  Stated tolerance: rel-L2 <= 2.5e-2 on
+    the final latents (one forward is ~1e-2; the DDPM update damps it: the tiny-topology drift test ends at 6.5e-3 after the same
+    20 steps), and no step multiplies the accumulated error by more than 1.5 (+2e-3).  ~55 s of CPU oracle on 16 threads."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mvd_amd.pipeline import MVDDenoiser
+    from mvd_amd.scheduler import DDPMScheduler, ShiftSNRScheduler
+    from oracle import scheduler as OS
+    from tests.parity_util import make_inputs, rel_l2, shared_pair
+    cfg, params, model = shared_pair("sd21")
+    inp = make_inputs(cfg, 1, 64, 77, seed=43, cam_dim=1024)
+    sched = ShiftSNRScheduler.from_scheduler(DDPMScheduler(), "interpolated", shift_scale=6.0, scheduler_class=DDPMScheduler)
+    steps, gs = 20, 1.0
+    g = torch.Generator().manual_seed(8)
+    noises = [torch.randn(1, 4, 64, 64, generator=g) for _ in range(steps)]
+    lat0 = torch.randn(1, 4, 64, 64, generator=g)
+    want_tr = []
+    OS.denoise_loop(params, cfg, sched.betas, inp["text"], None, lat0, inp["src"], inp["tgt"], inp["lat"], steps, gs, noises,
+                    [inp["proj"]] * steps, trace=want_tr, img_ref_scale=0.3, cam_modulation_strength=0.2)
+    model.fourier_projection = inp["proj"]
+    got_tr = []
+    try:
+        den = MVDDenoiser(model, sched)
+        den(inp["text"].cuda(), steps, gs, latents=lat0.cuda(), source_camera=inp["src"].cuda(), target_camera=inp["tgt"].cuda(),
+            source_image_latents=inp["lat"].cuda(), noise_per_step=[n.cuda() for n in noises],
+            callback=lambda i, t, l: got_tr.append(l.float().cpu().clone()))
+    finally:
+        model.fourier_projection = None
+    assert len(got_tr) == steps == len(want_tr)
+    errs = [rel_l2(a, b) for a, b in zip(got_tr, want_tr)]
+    print("full-size 20-step guidance-1.0 loop, rel-L2 per step = " + " ".join(f"{e:.1e}" for e in errs), flush=True)
+    assert all(torch.isfinite(t).all() for t in got_tr)
+    assert errs[-1] <= 2.5e-2, errs[-5:]
+    for i in range(1, steps):
+        assert errs[i] <= 1.5 * errs[i - 1] + 2e-3, (i, errs[i - 1], errs[i])

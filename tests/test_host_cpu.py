@@ -201,19 +201,29 @@ def test_utils_log_debug_and_dirs(tmp_path):
     log_debug(str(tmp_path / "missing_dir" / "x.log"), "does not raise")
 
 
-def test_gpu_session_time_budget_guard(monkeypatch):
-    """tests/conftest.py::oracle_time_budget: a heavy CPU-oracle test skips (with the reason) only when starting it would eat
-    into the reserve of the 900 s GPU session; the clock is shared by both import names of conftest."""
-    import time
-    import pytest
+def test_headline_parity_tests_cannot_drop_out_of_a_gpu_session():
+    """tests/conftest.py: a GPU session that collected the tests carrying configs[1..3] fails unless each of them PASSED (the
+    round-4 time-budget guard that let them skip is gone); partial runs and CPU sessions are not held to it; every name in the
+    list is a test that exists."""
+    import ast
     from tests import conftest as C
-    monkeypatch.setattr(C, "_SESSION_T0", time.time() - 100.0)
-    C.oracle_time_budget(130)                                    # 230 s < 600 s: runs
-    monkeypatch.setattr(C, "_SESSION_T0", time.time() - 500.0)
-    C.oracle_time_budget(45)                                     # 545 s < 600 s: runs
-    with pytest.raises(pytest.skip.Exception, match="time budget of the GPU session"):
-        C.oracle_time_budget(130)                                # 630 s > 600 s: skips
-    assert float(os.environ["MVD_GPU_SUITE_T0"]) <= time.time()
+    assert not hasattr(C, "oracle_time_budget")
+    allt = set(C.MUST_PASS_ON_GPU)
+    ok = {t: "passed" for t in allt}
+    assert C.missing_headline_tests(allt, ok, True) == []
+    one = sorted(allt)[0]
+    assert C.missing_headline_tests(allt, {**ok, one: "skipped"}, True) == [f"{one}: skipped"]
+    assert C.missing_headline_tests(allt, {k: v for k, v in ok.items() if k != one}, True) == [f"{one}: did not run"]
+    assert C.missing_headline_tests(allt, {}, False) == []                        # no GPU: the -m "not gpu" session
+    assert C.missing_headline_tests(allt - {one}, {}, True) == []                  # a partial selection
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for t in allt:
+        path, name = t.split("::")
+        tree = ast.parse(open(os.path.join(root, path)).read())
+        fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == name]
+        assert fn, t
+        src = ast.get_source_segment(open(os.path.join(root, path)).read(), fn[0])
+        assert "pytest.skip(\"needs a GPU\")" in src or "pytest.skip" not in src, t   # the only skip left: no GPU at all
 
 
 def test_oracle_host_threads_respects_the_cgroup_quota(monkeypatch):

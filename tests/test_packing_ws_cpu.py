@@ -42,10 +42,13 @@ def test_pack_unet_registers_ws_twins_for_every_level_but_the_first():
     packed = pack_unet(sd, cfg, "cpu", adapter=False)
     first = cfg.block_out_channels[0]
     seen = 0
+    split = cfg.resnet_input_split()
     for key, cin, cout in cfg.resnets():
         has1, has2 = f"{key}.conv1.ws" in packed, f"{key}.conv2.ws" in packed
+        c0, c1 = split[key]
+        assert c0 + c1 == cin and (c1 == 0) == (not key.startswith("up_blocks.")), key
         assert has1 == (cout > first and cout % 128 == 0 and cin % 128 == 0), key
-        assert has2 == (cout > first and cout % 128 == 0 and (cin == cout or cin % 128 == 0)), key
+        assert has2 == (cout > first and cout % 128 == 0 and (cin == cout or (c0 % 128 == 0 and c1 % 128 == 0))), key
         if has1:
             assert packed[f"{key}.conv1.ws"].numel() == cout * 9 * cin
         if has2:
@@ -77,3 +80,33 @@ def test_pack_unet_without_small_batch_twins_keeps_only_what_many_image_batches_
         assert torch.equal(t, full[k]), k
     nbytes = lambda d: sum(t.numel() * t.element_size() for t in d.values())   # noqa: E731
     assert nbytes(lean) < nbytes(full)
+
+
+def test_every_packed_ws_twin_is_reachable_from_the_engine():
+    """a ``.ws`` twin is packed only where conv_ws.hip's shape predicate (``mvd_conv_ws_applicable``: C % 128, N % 16,
+    EACH shortcut source % 128) can say yes for the resnet's real operands -- walked over the SD-2.1 configuration and over one
+    whose skip halves are not multiples of 128 (where the concatenated width still is), with the engine's work-item cap
+    (``try_ws``: (M / 64) * (N / 16) <= 1000) at the map sizes of a batch-1 forward on 64 x 64 latents."""
+    from mvd_amd.config import UNetConfig
+    from mvd_amd.packing import ws_twin_shapes_ok
+    for cfg in (UNetConfig.sd21(), UNetConfig(block_out_channels=(192, 320, 448, 448), num_heads=(3, 5, 7, 7))):
+        first = cfg.block_out_channels[0]
+        split = cfg.resnet_input_split()
+        level_hw = {c: 64 >> i for i, c in enumerate(cfg.block_out_channels)}
+        n_twins = 0
+        for key, cin, cout in cfg.resnets():
+            c0, c1 = split[key]
+            want1 = cout > first and ws_twin_shapes_ok(cin, cout, 0, 0)
+            want2 = cout > first and (ws_twin_shapes_ok(cout, cout, 0, 0) if cin == cout else ws_twin_shapes_ok(cout, cout, c0, c1))
+            if cin != cout and cin % 128 == 0 and (c0 % 128 or c1 % 128):
+                assert not want2, key                      # the case the advisor named: 640 + 320-style splits
+            n_twins += want1 + want2
+            if want2 and cin != cout:
+                assert c0 % 128 == 0 and c1 % 128 == 0, key
+        assert n_twins >= 8, n_twins
+    # SD-2.1 at one 64 x 64 latent: every twin the packer emits is taken at some level by the engine's work-item cap
+    cfg = UNetConfig.sd21()
+    for key, cin, cout in cfg.resnets():
+        if cout > cfg.block_out_channels[0]:
+            side = 64 >> max(i for i, c in enumerate(cfg.block_out_channels) if c == cout)      # the smallest map of that width
+            assert (side * side // 64) * (cout // 16) <= 1000, key

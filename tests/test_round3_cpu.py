@@ -23,7 +23,11 @@ def test_bench_gpus2_starts_two_ranks_itself():
     assert len(lines) == 1, r.stdout
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1
-    assert line["weight_broadcast"]["bytes"] > 0 and line["broadcast_ok"] is True
+    # the exact byte count of the two arenas (300 x 64 bf16 weights + 300 fp32 biases, each slot padded to the arena's 256-byte grid)
+    from mvd_amd import distributed as D
+    arenas, _ = D.pack_into_arenas({"a.w": torch.zeros(300, 64, dtype=torch.bfloat16), "a.b": torch.zeros(300)})
+    assert line["weight_broadcast"]["bytes"] == sum(a.numel() * a.element_size() for a in arenas.values()) >= 300 * 64 * 2 + 300 * 4
+    assert line["broadcast_ok"] is True and line["weight_broadcast"]["buckets"] == len(arenas)
     assert line["ms_per_step"] >= 20.0        # the max over ranks (rank 1 sleeps 20 ms), not rank 0's own 10 ms
     # round 4: who took part.  Two ranks = two processes with their LOCAL_RANKs; the collective library is named
     assert line["weight_broadcast"]["backend"] == "gloo" and line["weight_broadcast"]["rehearsal"] is True
@@ -44,6 +48,21 @@ def test_device_identity_helpers():
     clones = [{"local_rank": r, "uuid": "GPU-a", "pci_bus_id": str(10 + r), "device": r} for r in range(8)]
     assert D.distinct_devices(clones) == 8
     assert D.distinct_devices([{"local_rank": 0, "pid": 11}, {"local_rank": 1, "pid": 12}]) == 2    # CPU rehearsal
+    # with real (differing) UUIDs the key is (host, UUID) alone -- one physical GPU reached through two visibility
+    # masks / device indices counts ONCE, and equal tuples on two hosts count twice; the identity carries the host name
+    masks = [{"host": "n0", "uuid": "GPU-a", "device": 0}, {"host": "n0", "uuid": "GPU-a", "device": 1},
+             {"host": "n0", "uuid": "GPU-b", "device": 0}]
+    assert D.distinct_devices(masks) == 2
+    hosts = [{"host": "n0", "uuid": "GPU-a", "device": 0}, {"host": "n1", "uuid": "GPU-a", "device": 0},
+             {"host": "n1", "uuid": "GPU-b", "device": 1}]
+    assert D.distinct_devices(hosts) == 3
+    nouuid = [{"host": "n0", "pci_bus_id": "5", "device": 0}, {"host": "n1", "pci_bus_id": "5", "device": 0}]
+    assert D.distinct_devices(nouuid) == 2
+    zeros = [{"host": "n0", "uuid": "00000000-0000-0000-0000-000000000000", "device": r} for r in range(4)] + \
+            [{"host": "n0", "uuid": "GPU-b", "device": 4}]
+    assert D.distinct_devices(zeros) == 5           # a degenerate UUID among them: every rank falls back to the PCI / index key
+    import socket
+    assert D.device_identity(0)["host"] == socket.gethostname()
     D.check_enough_devices(8, rehearsal=True)                        # a rehearsal may oversubscribe one GPU
     D.check_enough_devices(8)                                        # no GPU visible: nothing to check (CPU control-flow tests)
 
@@ -144,19 +163,71 @@ def test_hand_pipelined_gemms_use_no_scratch_memory(name):
     assert not re.search(r"\.vgpr_spill_count:\s*[1-9]", asm) and not re.search(r"\.private_segment_fixed_size:\s*[1-9]", asm)
 
 
-def test_built_library_holds_no_packed_fp32_arithmetic():
-    """Round 4 traced the four-pixel conv_out's run-to-run differences on a shared GPU to hipcc's SLP-vectorised
-    `v_pk_fma_f32 ... op_sel:[0,1,0]`: the product is built with packed fp32 selection off, and the library that
-    ships (the one build() just produced) is disassembled here to prove no v_pk_{fma,mul,add}_f32 is left in any code object."""
+def _lint():
     import importlib.util
-    from mvd_amd import _build as B
-    lib = B.build()
     spec = importlib.util.spec_from_file_location("lint_device_isa", os.path.join(ROOT, "tools", "lint_device_isa.py"))
     lint = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(lint)
-    res = lint.count_packed_fp32(lib)
-    assert res["code_objects"] == len(B.SOURCES) and res["instructions"] > 100000
-    assert res["packed_fp32"] == 0, res
+    return lint
+
+
+def test_built_library_keeps_the_hand_scheduling_invariants():
+    """tools/lint_device_isa.py on the library that ships (the one build() just produced) and on the compiler's assembly of
+    conv_ws.hip / attention.hip -- invariants I1..I5 of DESIGN.md section 0: no packed fp32 arithmetic (the precaution of DESIGN 4.3), no
+    scratch / VGPR spills in any shipped kernel, every conv_ws ring-slot refill behind the retired read of that slot, every
+    asm-issued MFMA behind its own s_nop, every SGPR-soffset 16-byte store followed by its wait states."""
+    from mvd_amd import _build as B
+    lint = _lint()
+    lib = B.build()
+    summary, bad = lint.lint_all(lib)
+    assert summary["code_objects"] == len(B.SOURCES) and summary["instructions"] > 100000 and summary["kernels"] > 100, summary
+    assert summary["packed_fp32"] == 0 and summary["conv_ws_refill_fences"] >= 50 and summary["asm_issued_mfma"] >= 4, summary
+    assert summary["soffset_stores"] > 100, summary
+    assert not bad, bad[:10]
+    assert lint.count_packed_fp32(lib)["packed_fp32"] == 0
+
+
+def test_isa_lint_catches_what_it_is_there_for():
+    """The lint's own negative cases, on hand-written assembly: a ring refill hoisted above the retirement of its slot's read (round
+    4's conv_ws race), a wait that is too weak, a scalar load in flight, a missing fence, an asm MFMA without its s_nop, a
+    rewritten store-data register without wait states, a kernel with scratch."""
+    lint = _lint()
+    ok = """
+kern:
+\tds_read_b128 v[48:51], v47 offset:2048
+\tds_read_b128 v[56:59], v70 offset:18432
+\ts_waitcnt lgkmcnt(1)
+\tv_mfma_f32_16x16x32_bf16 a[0:3], v[48:51], v[56:59], a[0:3]
+\t;;#ASMSTART
+\t; MVD_REFILL_FENCE v[48:51]
+\t;;#ASMEND
+\tbuffer_load_dwordx4 v2, s[4:7], s10 offen lds
+"""
+    assert lint.check_refill_fences(ok) == (1, [])
+    hoisted = ok.replace("\ts_waitcnt lgkmcnt(1)\n", "")                       # the DMA's fence right behind the read's ISSUE
+    n, bad = lint.check_refill_fences(hoisted)
+    assert n == 1 and len(bad) == 1 and "has not retired" in bad[0]
+    weak = ok.replace("lgkmcnt(1)", "lgkmcnt(2)")                               # two may still be in flight: the slot's read too
+    assert "has not retired" in lint.check_refill_fences(weak)[1][0]
+    smem = ok.replace("\ts_waitcnt lgkmcnt(1)", "\ts_load_dword s3, s[0:1], 0x0\n\ts_waitcnt lgkmcnt(1)")
+    assert "scalar load" in lint.check_refill_fences(smem)[1][0]
+    assert "only 0 MVD_REFILL_FENCE" in lint.check_refill_fences(ok.replace("; MVD_REFILL_FENCE v[48:51]", ""))[1][0]
+    other = ok.replace("MVD_REFILL_FENCE v[48:51]", "MVD_REFILL_FENCE v[90:93]")
+    assert "no ds_read filled it" in lint.check_refill_fences(other)[1][0]
+
+    asm_ok = "\t;;#ASMSTART\n\ts_nop 1\n\tv_mfma_f32_32x32x16_bf16 v[68:83], v[56:59], v[84:87], v[36:51]\n\t;;#ASMEND\n"
+    assert lint.check_asm_mfma(asm_ok) == (1, [])
+    assert len(lint.check_asm_mfma(asm_ok.replace("\ts_nop 1\n", ""))[1]) == 1
+    assert len(lint.check_asm_mfma(asm_ok.replace("s_nop 1", "s_nop 0"))[1]) == 1
+    assert "only 0 asm-issued" in lint.check_asm_mfma("\tv_mfma_f32_32x32x16_bf16 v[0:15], v[56:59], v[84:87], v[0:15]\n")[1][0]
+
+    st = "buffer_store_dwordx4 v[156:159], v164, s[8:11], s40 offen"
+    assert lint.check_store_hazard([st, "s_nop 1", "v_mov_b32_e32 v157, v3"], "k") == []
+    assert lint.check_store_hazard([st, "s_waitcnt lgkmcnt(2)", "v_add_f32_e32 v1, v2, v3", "v_mov_b32_e32 v157, v3"], "k") == []
+    assert len(lint.check_store_hazard([st, "v_mov_b32_e32 v157, v3"], "k")) == 1
+    assert len(lint.check_store_hazard([st, "s_nop 0", "ds_read_b128 v[156:159], v1"], "k")) == 1
+    assert lint.check_store_hazard([st.replace("s40 offen", "0 offen"), "v_mov_b32_e32 v157, v3"], "k") == []      # no SGPR soffset
+    assert lint.check_store_hazard([st, "v_mov_b32_e32 v160, v3", "v_mov_b32_e32 v161, v3", "v_mov_b32_e32 v157, v3"], "k") == []
 
 
 def test_block_weight_layout_is_the_lds_image():
