@@ -218,8 +218,13 @@ int mvd_gemm_num_configs(void);
  * persistent multi-tile path (work items > workgroups) is what ran at the benchmarked shapes. */
 int mvd_debug_last_gemm_plan(int* out);
 int mvd_debug_last_attention_plan(int* out);
+/* 1 when the calling thread's last small-M split-K launch used the no-wait combine (requested, or chosen because the grid
+ * cannot be resident at once), else 0. */
+int mvd_debug_last_gemm_nowait(void);
 /* The split-K factor the engine's schedule picks for a GEMM/conv of this size (1 = none). */
 int mvd_debug_pick_splitk(int m, int n, int k, int geglu);
+/* The same for a 3x3 convolution run as an implicit GEMM (k = 9 * Cin + fused shortcut channels). */
+int mvd_debug_pick_splitk_conv(int m, int n, int k);
 /* Small-M kernels (gemm_sm.hip, the batch-1 path): force_cfg = 100 + 10 * tile + ring depth in mvd_op_linear / mvd_op_conv3x3
  * (tiles 0..6 = 64x64, 128x64, 64x128, 128x128, 64x160, 128x160, 64x320; + 1000: the weight is in the blocked LDS-image
  * layout of mvd_amd.packing.block_weight).  With splitk > 1 these kernels combine the slices themselves: splitk_ws then

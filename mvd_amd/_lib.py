@@ -101,8 +101,10 @@ _SIGS = {
     "mvd_op_f32_to_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "mvd_gemm_num_configs": (C.c_int, []),
     "mvd_debug_last_gemm_plan": (C.c_int, [C.POINTER(C.c_int)]),
+    "mvd_debug_last_gemm_nowait": (C.c_int, []),
     "mvd_debug_last_attention_plan": (C.c_int, [C.POINTER(C.c_int)]),
     "mvd_debug_pick_splitk": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mvd_debug_pick_splitk_conv": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "mvd_gemm_sm_num_tiles": (C.c_int, []),
     "mvd_debug_set_attention_nw": (C.c_int, [C.c_int]),
     "mvd_debug_set_flags": (C.c_int, [C.c_int]),

@@ -54,10 +54,12 @@ template <int WD, int RB, bool UPS> struct WsGeom {
   static constexpr int WI = UPS ? WD / 2 : WD; // input map width
   static constexpr int SR = UPS ? RO / 2 + 2 : RO + 2;   // input rows a block touches: its own + one halo row above and below
   static constexpr int SPX = SR * WI;          // slab pixels
-  static constexpr int NSL = SPX / 16;         // 1 KB DMA pieces per slab (16 pixels x 64 bytes)
-  static constexpr int SLAB = SPX * 64 + 64;   // + the zero row
+  static constexpr int NSL = (SPX + 15) / 16;  // 1 KB DMA pieces per slab (16 pixels x 64 bytes); on a 12-wide map the last piece
+                                               // runs 8 pixels past the slab's rows (real, clamped loads that nothing reads)
+  static constexpr int SPXP = NSL * 16;        // slab pixels incl. that padding: the zero row sits behind them
+  static constexpr int SLAB = SPXP * 64 + 64;  // + the zero row
   static constexpr int WAVE_BYTES = WS_RING * 1024 + NBUF * SLAB;
-  static_assert(BM % WD == 0 && SPX % 16 == 0 && 4 * WAVE_BYTES <= 160 * 1024 && (!UPS || RO % 2 == 0), "geometry");
+  static_assert(BM % WD == 0 && 4 * WAVE_BYTES <= 160 * 1024 && (!UPS || RO % 2 == 0), "geometry");
 };
 
 // One pass over `R` rounds of 128 input channels with T taps each.  svo[i]: the lane's global byte offset of slab piece i
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(const MvdWsArgs a) {
 
   unsigned char* const wbase = smem + wave * G::WAVE_BYTES;
   // zero rows of the slabs (a lane writes 4 bytes: 16 lanes per row)
-  if (lane < 16 * NBUF) *reinterpret_cast<unsigned*>(wbase + WS_RING * 1024 + (lane >> 4) * SLAB + G::SPX * 64 + (lane & 15) * 4) = 0u;
+  if (lane < 16 * NBUF) *reinterpret_cast<unsigned*>(wbase + WS_RING * 1024 + (lane >> 4) * SLAB + G::SPXP * 64 + (lane & 15) * 4) = 0u;
 
   const int Rc = a.C / 128, Rs0 = a.scc0 / 128, Rs1 = a.scc1 / 128;
   const unsigned tile_bytes = (unsigned)((Rc * 9 + Rs0 + Rs1) * 4) * 1024u;            // packed bytes of one column tile
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(const MvdWsArgs a) {
         const bool inside = (unsigned)ux < (unsigned)WD && (unsigned)uy < (unsigned)OH;
         const int iy = UPS ? uy >> 1 : uy, ix = UPS ? ux >> 1 : ux;
         const int q = (iy - iy_lo) * G::WI + ix;                        // slab pixel
-        aoff[t][rb] = inside ? q * 64 + 16 * (lh ^ ((q >> 2) & 3)) : G::SPX * 64 + 16 * lh;
+        aoff[t][rb] = inside ? q * 64 + 16 * (lh ^ ((q >> 2) & 3)) : G::SPXP * 64 + 16 * lh;
       }
     }
     const unsigned wso = (unsigned)ct * tile_bytes + (unsigned)(wave * 9) * 1024u;
@@ -235,8 +237,9 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(const MvdWsArgs a) {
   for (int rb = 0; rb < RB; ++rb) red[(wave * RB + rb) * 64 + lane] = acc[rb];
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < RB / 4; ++j) {
+  for (int j = 0; j < (RB + 3) / 4; ++j) {
     const int rb = wave + 4 * j;
+    if (rb >= RB) break;                                   // (RB = 3, 6: the 12- and 24-wide maps)
     f32x4 v = red[(0 * RB + rb) * 64 + lane];
 #pragma unroll
     for (int w = 1; w < 4; ++w) v += red[(w * RB + rb) * 64 + lane];
@@ -252,7 +255,8 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(const MvdWsArgs a) {
   }
 }
 
-// variants: 1 = 64-pixel blocks (8-, 16-, 32-wide maps); 2 = 128-pixel blocks (16-wide maps: half the weight re-reads of variant 1)
+// variants: 1 = 64-pixel blocks (8-, 16-, 32-wide maps); 2 = 128-pixel blocks (16-wide maps: half the weight re-reads of variant 1);
+// 3 = 48- / 96-pixel blocks (12- / 24-wide maps)
 template <int WD, int RB, bool UPS>
 int launch_ws(const MvdWsArgs& a, hipStream_t s, bool* lds_set) {
   using G = WsGeom<WD, RB, UPS>;
@@ -270,7 +274,7 @@ int launch_ws(const MvdWsArgs& a, hipStream_t s, bool* lds_set) {
   return 0;
 }
 
-bool g_ws_lds_set[16][8];
+bool g_ws_lds_set[16][12];
 
 }  // namespace
 
@@ -279,9 +283,14 @@ static int ws_variant(const MvdWsArgs& a) {
   const int ow = a.ups ? 2 * a.W : a.W, hw = (a.ups ? 4 : 1) * a.H * a.W;          // output map width / pixels
   const bool ok1 = a.ups ? (ow == 16 || ow == 32) && hw % 64 == 0 : (ow == 8 || ow == 16 || ow == 32) && hw % 64 == 0;
   const bool ok2 = ow == 16 && hw % 128 == 0;
+  // variant 3 (round 5): the maps of a 96 x 96 latent (the reference's 768 x 768 default, infer.py:187) -- 12 wide in 48-pixel
+  // blocks (4 rows), 24 wide in 96-pixel blocks (4 rows); the 12 -> 24 upsampling form.  (48 wide is beyond try_ws's work-item cap.)
+  const bool ok3 = a.ups ? ow == 24 && hw % 96 == 0 : (ow == 12 && hw % 48 == 0) || (ow == 24 && hw % 96 == 0);
   if (a.variant == 1) return ok1 ? 1 : 0;
   if (a.variant == 2) return ok2 ? 2 : 0;
+  if (a.variant == 3) return ok3 ? 3 : 0;
   if (a.variant) return 0;
+  if (ok3) return 3;
   if (ok2 && a.M >= 256) return 2;      // one 16x16 map or more: 128-pixel blocks halve the weight re-reads and fit one wave of workgroups
   return ok1 ? 1 : 0;
 }
@@ -316,6 +325,9 @@ int mvd_launch_conv_ws(const MvdWsArgs& a, hipStream_t s) {
     case 1116: return launch_ws<16, 4, true>(a, s, f + 4);
     case 1132: return launch_ws<32, 4, true>(a, s, f + 5);
     case 1216: return launch_ws<16, 8, true>(a, s, f + 6);
+    case 312: return launch_ws<12, 3, false>(a, s, f + 7);
+    case 324: return launch_ws<24, 6, false>(a, s, f + 8);
+    case 1324: return launch_ws<24, 6, true>(a, s, f + 9);
   }
   mvd_set_error("conv_ws: no kernel for variant %d at map width %d", ws_variant(a), a.W);
   return -1;

@@ -25,6 +25,7 @@ int mvd_launch_silu_to_bf16(const float* x, int64_t n, bf16_t* y, hipStream_t s)
 // bit 7 (128) = X-stationary kernels off
 static int g_debug_flags = 0;
 extern "C" int mvd_debug_set_flags(int flags) { g_debug_flags = flags; return 0; }
+int mvd_debug_flags() { return g_debug_flags; }
 
 namespace {
 
@@ -309,8 +310,8 @@ struct Ctx {
     int fc = -1;
     if (e->dual_now && !(g_debug_flags & 32) && !g.geglu && !g.ln_c1 && !g.out_f32 && g.N % 320 == 0 && mvd_gemm_pp_applicable(g)) {
       const int cfg = mvd_gemm_pick_config(g);
-      if (cfg == 7) S = 1;
-      else if ((long)((g.M + 255) / 256) * (g.N / 320) >= 100) { fc = 7; S = 1; }
+      const long t7 = (long)((g.M + 255) / 256) * (g.N / 320);
+      if (t7 >= 100) { S = 1; if (cfg != 7) fc = 7; }      // (below 100 tiles -- the 8x8 level -- the heuristic's tile and split stand)
     }
     const size_t mark = e->tmp.off;
     if (S > 1) { g.splitk = S; g.part = talloc<float>((size_t)S * g.M * g.N); }
@@ -999,9 +1000,12 @@ int forward_body(mvd_engine* e, const mvd_forward_args_t& a, hipStream_t s, bool
   // ---- the encoder pass goes to the side stream (see mvd_engine::side): at batch 1 the two passes overlap almost completely
   // (cfg3 cold 9.8 -> 7.0 ms), at 32 pairs the second stream still fills the tails and the under-filled launches of the deep
   // levels (cfg4 65.0 -> 63.5 ms, same box).  `dual` (a function of the call's flags only) decides the workspace layout -- in
-  // the sizing runs too; whether the side stream is really used also needs: no graph capture, no per-launch profiling.
+  // the sizing runs too; whether the side stream is really used also needs: no per-launch profiling.
   const bool dual = use_img && !reuse && !ref_only;
-  e->dual_now = dual && !dry && !e->graph_on && (!e->prof || e->prof_overlap) && !(g_debug_flags & 16);
+  // (Round 5: under hipGraph capture too.  The fork event is recorded on the capturing stream and waited for by the side stream,
+  //  which thereby joins the capture; the per-feature events and the join event become edges of the graph, so a replayed
+  //  forward keeps the two-branch schedule instead of serialising the passes.  Debug flag 65536 restores the one-stream capture.)
+  e->dual_now = dual && !dry && !(e->graph_on && (g_debug_flags & 65536)) && (!e->prof || e->prof_overlap) && !(g_debug_flags & 16);
   if (e->dual_now) {   // fork in front of everything else: the encoder pass needs nothing of the camera path
     CHECK(e->ensure_side_stream());
     if (hipEventRecord(e->fork_ev, s) != hipSuccess || hipStreamWaitEvent(e->side, e->fork_ev, 0) != hipSuccess) { mvd_set_error("forward: stream fork failed"); return -3; }

@@ -21,7 +21,7 @@
 #include <string.h>
 #include "kernels.h"
 
-thread_local MvdLaunchPlan g_mvd_last_gemm = {-1, 1, 0, 0, 0};
+thread_local MvdLaunchPlan g_mvd_last_gemm = {-1, 1, 0, 0, 0, 0};
 
 namespace {
 
@@ -574,9 +574,24 @@ extern "C" int mvd_debug_last_gemm_plan(int* out) {
   return 0;
 }
 
+// 1 when the calling thread's last small-M split-K launch took the no-wait combine (asked for by the caller, or because its
+// grid exceeded what the chip holds at once: gemm_sm.hip launch_sm3), else 0
+extern "C" int mvd_debug_last_gemm_nowait(void) { return g_mvd_last_gemm.nowait; }
+
 // Tile choice (tools/tune_gemm.py sweep on MI355X, profiles/r01_tune_gemm_B32_v2.log): the 256x320 tile wins wherever
 // its grid (times a split-K of at most 2) can occupy the 256 CUs; below that, fall through 128x160 -> 128x128 ->
 // 128x64 -> 64x64 until the grid has >= ~300 workgroups, else take the config with the most workgroups.
+// split factor of the rule above (1: the rule does not apply)
+static int deep_conv_split(const MvdGemmArgs& a, long t7) {
+  static const int on = MVD_ENV_INT("MVD_GEMM_DEEP_CONV_SPLIT", 1);
+  // (a.splitk: 0 = undecided, the engine asks mvd_gemm_pick_splitk first; a caller that fixed a shallow split -- the operator entry
+  //  points with their default splitk = 1 -- keeps the tile that suits it: 32 unsplit 256x320 tiles would leave 224 CUs idle)
+  if (!on || a.seg[0].mode == MVD_A_DENSE || a.geglu || a.out_f32 || t7 < 24 || t7 > 64 || a.Ktot < 8192 || (a.splitk > 0 && a.splitk < 4)) return 1;
+  int s = (int)(256 / t7);
+  while (s > 1 && a.Ktot / 64 / s < 16) --s;
+  return s > 16 ? 16 : s;
+}
+
 int mvd_gemm_pick_config(const MvdGemmArgs& a) {
   // 256x320 tile with 128x80 wave tiles (49 FLOP per LDS-read byte): the kernel is LDS-bandwidth bound, so this
   // is the fastest shape whenever its tile grid -- times a split-K of up to 8 -- can occupy the 256 CUs
@@ -596,6 +611,10 @@ int mvd_gemm_pick_config(const MvdGemmArgs& a) {
     // (measured at M 8192 x N 1280: K 1280 36 us vs 41 + 15 us, K 2560 67 vs 63 + 15 us, K 5120 a tie; end to end the
     //  rule is worth 0.2-0.5 %)
     else if (a.Ktot / 64 >= split_min_slabs && t7 * 2 >= 200) return 7;
+    // the 3x3 convolutions of the 8x8 level at 32 images (M = 2048: 32 tiles, K = 11520 ... 23040): the big tile cut EIGHT ways
+    // along K (256 workgroups, each slice >= 22 slabs) beats 512 work items of the 128x160 tile at split 4 by 7 / 16 / 3 %
+    // (tools/tune_worst_shapes.py, profiles/r04_tune_worst_shapes.log) -- half the operand bytes per FLOP, same partial traffic
+    else if (deep_conv_split(a, t7) > 1) return 7;
   }
   static const int order[] = {2, 3, 4, 5};
   int cfg = -1, first_valid = -1;
@@ -715,6 +734,7 @@ int mvd_gemm_pick_splitk(const MvdGemmArgs& a) {
   if (cfg < 0) return 1;
   const long tiles = (long)((a.M + kCfgs[cfg].bm - 1) / kCfgs[cfg].bm) * (a.N / kCfgs[cfg].bn);
   const int nkt = a.Ktot / 64;
+  if (cfg == 7 && deep_conv_split(a, tiles) > 1) return deep_conv_split(a, tiles);
   if (cfg == 7 || cfg == 8) return (tiles >= 200 || nkt < 16) ? 1 : 2;   // one 115-147 KB workgroup per CU
   if (tiles >= 256 || nkt < 16) return 1;
   long s = 512 / tiles;                                       // two workgroups per CU
@@ -732,6 +752,12 @@ int mvd_gemm_pick_splitk(const MvdGemmArgs& a) {
 extern "C" int mvd_debug_pick_splitk(int m, int n, int k, int geglu) {
   MvdGemmArgs a; memset(&a, 0, sizeof(a));
   a.M = m; a.N = n; a.Ktot = k; a.geglu = geglu;
+  return mvd_gemm_pick_splitk(a);
+}
+// the same for a 3x3 convolution (implicit GEMM: K = 9 * Cin + shortcut channels) -- the 8x8-level rule is for convolutions only
+extern "C" int mvd_debug_pick_splitk_conv(int m, int n, int k) {
+  MvdGemmArgs a; memset(&a, 0, sizeof(a));
+  a.M = m; a.N = n; a.Ktot = k; a.seg[0].mode = MVD_A_CONV3;
   return mvd_gemm_pick_splitk(a);
 }
 

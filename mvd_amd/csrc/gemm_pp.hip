@@ -122,6 +122,19 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
   const int tend = tstart + tq + (xcd < tr ? 1 : 0);
   // (A contiguous sub-range per workgroup -- the N tiles of a row block one after the other instead of side by side -- was
   //  measured for every form: dense +3 %, fused-LayerNorm +6 %, GEGLU +7 % slower; convolutions and split-K within +-1 %.)
+  // Column-group walk (a.walk_cg = c > 0; unsplit launches whose XCD ranges are whole row blocks): local index i of the XCD's
+  // range -> group g = i / (rows * c), row (i % (rows * c)) / c, column g * c + i % c.  32 workgroups of an XCD then sit on
+  // 32 / c row blocks x c column tiles: the c weight panels are fetched once per XCD and group, not once per row-block pair.
+  const int wcg = SPLITK ? 0 : a.walk_cg;
+  const int xrows = (tend - tstart) / ntn, xrow0 = tstart / ntn;
+  auto tile_mn = [&](int t, int& m0, int& n0) {
+    if (wcg) {
+      const int li = t - tstart, per = xrows * wcg;
+      const int g = li / per, rem = li - g * per;
+      const int r = rem / wcg;
+      m0 = (xrow0 + r) * BM; n0 = (g * wcg + (rem - r * wcg)) * BN;
+    } else { m0 = (t / ntn) * BM; n0 = (t % ntn) * BN; }
+  };
   const int tile_first = tstart + xj, tile_end = tend, tile_step = gx;
   int tile = tile_first;
   if (tile >= tile_end) return;
@@ -162,8 +175,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
   int a_yx[A_IT];             // conv: (oy*stride) | (ox*stride) << 16 | in-image mask of the 9 taps << 22 (bit 22 + tap)
   auto setup_loader = [&](int work) {
     const int t = S == 1 ? work : work / S;
-    ld_m0 = (t / ntn) * BM;
-    ld_n0 = (t % ntn) * BN;
+    tile_mn(t, ld_m0, ld_n0);
     if (HAS_CONV) {
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) {
@@ -574,7 +586,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
   for (;;) {
     const int tl = S == 1 ? tile : tile / S;
     const int ks = S == 1 ? 0 : tile - tl * S;
-    const int m0 = (tl / ntn) * BM, n0 = (tl % ntn) * BN;
+    int m0, n0;
+    tile_mn(tl, m0, n0);
     const int next_tile = tile + tile_step;
     const bool have_next = next_tile < tile_end;
     int nkt0 = 0, nkt1 = 0;
@@ -645,11 +658,13 @@ int launch_pp(const MvdGemmArgs& a, hipStream_t s) {
     init[dev & 15] = true;
   }
   const int ntm = (a.M + BM - 1) / BM, ntn = a.N / BN;
+  MvdGemmArgs b = a;
+  b.walk_cg = SPLITK ? 0 : mvd_gemm_pp_walk(a);
   int grid = 256;                                         // one 144 KB (112 KB at BM = 128) workgroup per CU
   const int ntiles = ntm * ntn * (a.splitk > 1 ? a.splitk : 1);
   if (ntiles < grid) grid = ((ntiles + 7) / 8) * 8;
   g_mvd_last_gemm.tiles = ntiles; g_mvd_last_gemm.grid = grid; g_mvd_last_gemm.per_cu = 1;
-  hipLaunchKernelGGL((gemm_pp_kernel<BM, WM, WN, AMODE, SPLITK, LNF>), dim3(grid), dim3(NT), LDS_BYTES, s, a);
+  hipLaunchKernelGGL((gemm_pp_kernel<BM, WM, WN, AMODE, SPLITK, LNF>), dim3(grid), dim3(NT), LDS_BYTES, s, b);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { mvd_set_error("gemm_pp launch: %s", hipGetErrorString(e)); return -3; }
   return 0;
@@ -668,6 +683,27 @@ int launch_pp_mode(const MvdGemmArgs& a, hipStream_t s) {
 }
 
 }  // namespace
+
+// Column-group walk of the ping-pong kernel (MvdGemmArgs::walk_cg): for dense, unsplit launches whose weight operand does not
+// fit an XCD's 4 MB L2 beside the activation rows in flight, while every XCD owns >= 8 whole row blocks (M >= 16384: the 32x32
+// level at 32 images).  PMC before: the 32x32-level GEGLU (N 5120, K 640: W = 6.5 MB) read 13x its A + W -- with all 16 column
+// tiles of two row blocks side by side every XCD re-fetched every weight panel for every pair of row blocks.  c = the most
+// column tiles whose panels take <= 1.75 MB (the rest of the L2 holds 32 / c activation panels and the streaming output).
+// MVD_GEMM_PP_WALK=0 / debug flag 131072 turn it off (A/B).
+int mvd_gemm_pp_walk(const MvdGemmArgs& a) {
+  static const int on = MVD_ENV_INT("MVD_GEMM_PP_WALK", 1);
+  if (!on || (mvd_debug_flags() & 131072) || a.walk_cg < 0) return 0;
+  if (a.walk_cg > 0) return a.walk_cg;                         // forced (tests / probes)
+  if (a.seg[0].mode != MVD_A_DENSE || a.nseg != 1 || a.splitk > 1) return 0;
+  const int ntm = (a.M + 255) / 256, ntn = a.N / BN;
+  if (ntm % 8 || ntm < 64 || ntn < 8) return 0;
+  const size_t panel = (size_t)BN * a.Ktot * 2;
+  if (panel * ntn <= (size_t)(5 << 19)) return 0;              // W <= 2.5 MB: it stays in L2 as it is
+  int c = (int)(((size_t)7 << 18) / panel);                    // 1.75 MB of panels
+  if (c < 2) return 0;
+  while (c > 1 && (ntn % c || 32 % c)) --c;
+  return c >= 2 ? c : 0;
+}
 
 // Every byte offset the kernel forms must fit the 32-bit buffer addressing (and stay below OOB = 2^31).
 bool mvd_gemm_pp_applicable(const MvdGemmArgs& a) {

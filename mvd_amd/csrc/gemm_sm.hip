@@ -489,11 +489,26 @@ int launch_sm3(const MvdGemmArgs& a, int nstage, hipStream_t s) {
   const int ntm = (a.M + BM - 1) / BM, ntn = a.N / BN;
   const int S = a.splitk > 1 ? a.splitk : 1;
   const int grid = ntm * ntn * S;
-  // (no residency condition on a split-K grid: the in-kernel rendezvous is bounded and the last arriver combines whatever the
+  // (no residency CONDITION on a split-K grid: the in-kernel rendezvous is bounded and the last arriver combines whatever the
   //  others left, so slices that are not co-resident -- a grid beyond the chip, another tenant on the GPU -- cost time, not
-  //  correctness)
+  //  correctness.  But the time is ~1 ms of polling per waiting slice (4096 x s_sleep 8) before the missing slices can start, so
+  //  the occupancy query stays as a HINT: a grid that cannot be resident at once -- a forced split through mvd_op_* -- takes the
+  //  no-wait combine, where the last arriver sums the whole tile and nobody polls.  ADVICE r4.)
+  MvdGemmArgs b = a;
+  if constexpr (SPLITK) {
+    static int resident[16][9] = {};                    // per device and ring depth: workgroups the chip holds at once
+    int& cap = resident[dev & 15][nstage & 7];
+    if (!cap) {
+      int occ = 0, ncu = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gemm_sm_kernel<BM, BN, AMODE, SPLITK, GEGLU, LNF>, 256, lds) != hipSuccess || occ < 1) occ = 1;
+      if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1) ncu = 256;
+      cap = occ * ncu;
+    }
+    if (grid > cap) b.splitk_nowait = 1;
+  }
   g_mvd_last_gemm.tiles = grid; g_mvd_last_gemm.grid = grid; g_mvd_last_gemm.per_cu = 160 * 1024 / lds;
-  hipLaunchKernelGGL((gemm_sm_kernel<BM, BN, AMODE, SPLITK, GEGLU, LNF>), dim3(grid), dim3(256), lds, s, a, nstage);
+  g_mvd_last_gemm.nowait = b.splitk_nowait;
+  hipLaunchKernelGGL((gemm_sm_kernel<BM, BN, AMODE, SPLITK, GEGLU, LNF>), dim3(grid), dim3(256), lds, s, b, nstage);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { mvd_set_error("gemm_sm launch: %s", hipGetErrorString(e)); return -3; }
   return 0;

@@ -56,16 +56,22 @@ struct MvdGemmArgs {
   //   out = rstd[m] * (acc - mean[m] * ln_c1[n]) + bias[n]      ( = LayerNorm(x).W0^T + b )
   const float* ln_c1;     // [N] fp32 or null
   float ln_eps;
+  // gemm_pp.hip tile walk (set by the launcher, mvd_gemm_pp_walk): 0 = an XCD's workgroups stride through its row-major tile
+  // range (all column tiles of a row block side by side); c > 0 = the XCD's rows are walked in GROUPS of c column tiles -- the
+  // group's weight panels stay in the XCD's L2 while the rows stream past (short-K GEMMs whose W exceeds the 4 MB L2)
+  int walk_cg;
 };
 
 int mvd_launch_gemm(const MvdGemmArgs& a, hipStream_t s, int force_cfg = -1);
 int mvd_gemm_pick_config(const MvdGemmArgs& a);   // tile config the heuristic gives this problem
 // what the calling thread's last mvd_launch_gemm launched (tests assert that the persistent multi-tile path ran)
-struct MvdLaunchPlan { int cfg, splitk, tiles, grid, per_cu; };
+struct MvdLaunchPlan { int cfg, splitk, tiles, grid, per_cu, nowait; };
 extern thread_local MvdLaunchPlan g_mvd_last_gemm;
 // 256x320 "ping-pong" kernels (gemm_pp.hip): buffer-addressed LDS-DMA, two wave groups one phase apart.  Used for tile
 // configs 6 (GEGLU) and 7 whenever every byte offset fits 32-bit buffer addressing; arguments validated by mvd_launch_gemm.
 bool mvd_gemm_pp_applicable(const MvdGemmArgs& a);
+int mvd_gemm_pp_walk(const MvdGemmArgs& a);        // column tiles per group of the ping-pong kernel's tile walk (0: row-major)
+int mvd_debug_flags();                             // engine.hip: the measurement switches of mvd_debug_set_flags
 // true when a problem with a.ln_c1 set can run (one dense source spanning the whole row, no residual / row vector /
 // split-K, and a shape the heuristic gives to the ping-pong kernels); the engine falls back to ln_kernel + plain GEMM otherwise
 bool mvd_gemm_ln_fold_ok(const MvdGemmArgs& a);

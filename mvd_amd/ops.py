@@ -221,7 +221,7 @@ def last_gemm_plan():
     """dict(cfg, splitk, tiles, grid, per_cu) of this thread's last GEMM / conv launch."""
     out = (C.c_int * 5)()
     L.call("mvd_debug_last_gemm_plan", out)
-    return dict(cfg=out[0], splitk=out[1], tiles=out[2], grid=out[3], per_cu=out[4])
+    return dict(cfg=out[0], splitk=out[1], tiles=out[2], grid=out[3], per_cu=out[4], nowait=L.lib().mvd_debug_last_gemm_nowait())
 
 
 def last_attention_plan():
@@ -230,6 +230,8 @@ def last_attention_plan():
     return dict(waves=out[0], workgroups=out[1])
 
 
-def engine_splitk(m, n, k, geglu=False):
-    """The split-K factor the engine's schedule uses for this GEMM / conv size."""
+def engine_splitk(m, n, k, geglu=False, conv=False):
+    """The split-K factor the engine's schedule uses for this GEMM (or, ``conv=True``, 3x3 convolution) size."""
+    if conv:
+        return L.lib().mvd_debug_pick_splitk_conv(m, n, k)
     return L.lib().mvd_debug_pick_splitk(m, n, k, int(geglu))

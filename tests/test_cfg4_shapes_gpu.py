@@ -106,6 +106,30 @@ def test_geglu_cfg4_shapes(ops, m, c):
     close(got, want, tol=2 ** -6, what=f"geglu M={m} C={c}")
 
 
+@pytest.mark.parametrize("n,geglu", [(5120, True), (2560, False)])
+def test_column_group_tile_walk_is_bit_identical(ops, n, geglu):
+    """Round 5 (gemm_pp.hip, MvdGemmArgs::walk_cg): the 32x32-level launches whose weights exceed an XCD's L2 (GEGLU N 5120, the fused
+    q|k|v|q_ref N 2560; K = 640, M = 32768) walk an XCD's row blocks in groups of 4 column tiles instead of 16 / 8 side by side.
+    Same tiles, same arithmetic per tile: the output must equal the row-major walk's (debug flag 131072) bit for bit, and the fp32
+    reference within tolerance."""
+    from mvd_amd import _lib as L
+    from mvd_amd.packing import _geglu_rows
+    m, k = 32768, 640
+    a, w = grnd(m, k, seed=11), grnd(n, k, scale=1 / math.sqrt(k), seed=12)
+    bias = grnd(n, seed=13, dtype=torch.float32)
+    if geglu:
+        w, bias = _geglu_rows(w).contiguous(), _geglu_rows(bias).contiguous()
+    got = ops.linear(a, w, bias, geglu=geglu)
+    L.lib().mvd_debug_set_flags(131072)
+    try:
+        plain = ops.linear(a, w, bias, geglu=geglu)
+    finally:
+        L.lib().mvd_debug_set_flags(0)
+    assert torch.equal(got, plain), "the column-group walk changed the result"
+    if not geglu:
+        close(got, a.float() @ w.float().T + bias, what=f"walk linear {m}x{n}x{k}")
+
+
 # ------------------------------------------------------------------------------- implicit-GEMM convolutions at B = 32
 @pytest.mark.parametrize("hw,cin,cout,extra", [
     (64, 320, 320, "rowvec"),          # L0 resnet conv1 (+ time-embedding row vector): M 131072, K 2880
@@ -164,6 +188,34 @@ def test_conv_stride2_and_upsample_cfg4_shapes(ops):
     got = ops.conv3x3(x.permute(0, 2, 3, 1).contiguous(), _pack(w), bias, upsample=True)
     _assert_persistent(ops, 7, "upsample conv")
     close(got, want, what="upsample conv 640 @32^2->64^2")
+
+
+@pytest.mark.parametrize("cin,sc", [(1280, 0), (2560, 0), (1280, 2560)])
+def test_deep_level_conv_cfg4_shapes(ops, cin, sc):
+    """The 8x8 level at 32 images (M = 2048, K = 11520 ... 23040, mid block and up_blocks.0): round 5 runs these through the 256x320
+    tile cut EIGHT ways along K (256 workgroups) instead of 512 work items of the 128x160 tile at split 4 -- the split the
+    engine's heuristic picks, the launch plan it leads to, and the result against fp32 conv2d (+ the fused 1x1 shortcut)."""
+    hw, cout = 8, 1280
+    k = 9 * cin + sc
+    sk = ops.engine_splitk(B32 * hw * hw, cout, k, conv=True)
+    assert sk == 8, sk
+    x = grnd(B32, cin, hw, hw, seed=51)
+    w = grnd(cout, cin, 3, 3, scale=1 / math.sqrt(9 * cin), seed=52)
+    bias = grnd(cout, seed=53, dtype=torch.float32)
+    want = F.conv2d(x.float(), w.float(), bias, padding=1).permute(0, 2, 3, 1)
+    wp, kw = _pack(w), {}
+    if sc:
+        s1, s2 = grnd(B32, hw, hw, sc // 2, seed=54), grnd(B32, hw, hw, sc // 2, seed=55)
+        wsc = grnd(cout, sc, scale=1 / math.sqrt(sc), seed=56)
+        want = want + torch.cat([s1, s2], -1).float() @ wsc.float().T
+        wp, kw = torch.cat([wp, wsc], dim=1).contiguous(), dict(shortcut=s1, shortcut2=s2)
+    got = ops.conv3x3(x.permute(0, 2, 3, 1).contiguous(), wp, bias, splitk=sk, **kw)
+    plan = ops.last_gemm_plan()
+    assert plan["cfg"] == 7 and plan["splitk"] == 8 and plan["tiles"] == 8 * 4 * 8, plan
+    close(got, want, what=f"8x8-level conv {cin}->{cout} +sc{sc} split {sk}")
+    # the operator entry point's own default (no split asked for) keeps the 128x160 tile: 32 unsplit big tiles would idle 224 CUs
+    ops.conv3x3(x.permute(0, 2, 3, 1).contiguous(), wp, bias, **kw)
+    assert ops.last_gemm_plan()["cfg"] == 2, ops.last_gemm_plan()
 
 
 @pytest.mark.parametrize("kind", ["conv", "dense"])

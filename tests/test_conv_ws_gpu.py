@@ -1,6 +1,6 @@
 """Weight-streaming 3x3 convolution of small maps (mvd_amd/csrc/conv_ws.hip) vs a PyTorch fp32 conv2d of the same op on
 bf16-rounded inputs.  Tolerance |err| <= 2^-7 * max|ref| as for the other GEMM / conv kernels (tests/test_ops_gpu.py): the
-output is bf16, accumulation fp32 in a different order than the reference's.  Covers the three map widths (8, 16, 32) and both block heights, several images
+output is bf16, accumulation fp32 in a different order than the reference's.  Covers the map widths 8, 16, 32 (and 12, 24: the maps of a 96 x 96 latent) and the block heights of each, several images
 per launch, the fused dense shortcut with one and two sources, the time-embedding row vector, the residual, the map borders
 (a one-hot input makes every tap land on a known pixel) and agreement with the implicit-GEMM kernel the engine used before."""
 import math
@@ -46,13 +46,19 @@ def reference(x, w4, bias, wsc=None, sc=None, rowvec=None, res=None):
 
 
 def variants(h, w):
-    """kernel forms that take an h x w map: 0 = the launcher's choice, 1 = 64-pixel blocks, 2 = 128-pixel blocks (16-wide maps)"""
+    """kernel forms that take an h x w map: 0 = the launcher's choice, 1 = 64-pixel blocks, 2 = 128-pixel blocks (16-wide maps),
+    3 = 48- / 96-pixel blocks of the 12- / 24-wide maps of a 96 x 96 latent"""
+    if w in (12, 24):
+        return [0, 3]
     return [0, 1] + ([2] if w == 16 and (h * w) % 128 == 0 else [])
 
 
 @pytest.mark.parametrize("b,h,w,c,n", [(1, 8, 8, 1280, 1280), (1, 16, 16, 640, 1280), (2, 8, 8, 256, 64), (1, 16, 16, 128, 48),
                                        (3, 8, 8, 128, 16), (1, 8, 16, 256, 32), (2, 16, 16, 128, 160), (1, 32, 32, 640, 640),
-                                       (1, 4, 32, 128, 16), (1, 24, 16, 128, 32)])
+                                       (1, 4, 32, 128, 16), (1, 24, 16, 128, 32),
+                                       # round 5: the 12 x 12 and 24 x 24 maps of the reference's 768 x 768 default (96 x 96 latents)
+                                       (1, 12, 12, 1280, 1280), (1, 24, 24, 1280, 1280), (2, 12, 12, 256, 48), (1, 8, 24, 128, 32),
+                                       (3, 4, 12, 128, 16), (2, 24, 24, 128, 64)])
 def test_conv_ws_plain_rowvec_residual(ops, b, h, w, c, n):
     from mvd_amd.packing import pack_ws
     x, w4 = rnd(b, h, w, c, seed=1), rnd(n, c, 3, 3, scale=1 / math.sqrt(9 * c), seed=2)
@@ -66,7 +72,8 @@ def test_conv_ws_plain_rowvec_residual(ops, b, h, w, c, n):
 
 
 @pytest.mark.parametrize("b,h,w,c,n,s0,s1", [(1, 8, 8, 1280, 1280, 1280, 1280), (1, 16, 16, 1280, 1280, 640, 0), (2, 8, 8, 128, 64, 128, 256),
-                                             (1, 16, 16, 256, 32, 384, 0), (1, 32, 32, 128, 32, 256, 128)])
+                                             (1, 16, 16, 256, 32, 384, 0), (1, 32, 32, 128, 32, 256, 128),
+                                             (1, 12, 12, 1280, 1280, 1280, 1280), (1, 24, 24, 256, 64, 384, 128), (2, 12, 12, 128, 32, 256, 0)])
 def test_conv_ws_fused_shortcut(ops, b, h, w, c, n, s0, s1):
     """conv2 | conv_shortcut of a channel-changing resnet: the 1x1 shortcut over the block input (one tensor, or the two halves
     of a skip concatenation) is a second K segment of the same launch."""
@@ -83,7 +90,8 @@ def test_conv_ws_fused_shortcut(ops, b, h, w, c, n, s0, s1):
         close(got, reference(x, w4, bias, wsc=wsc, sc=sc), what=f"ws + shortcut, variant {v}")
 
 
-@pytest.mark.parametrize("b,h,w,c,n", [(1, 8, 8, 1280, 1280), (1, 16, 16, 256, 64), (2, 4, 8, 128, 48), (1, 2, 16, 128, 16), (3, 8, 8, 128, 32)])
+@pytest.mark.parametrize("b,h,w,c,n", [(1, 8, 8, 1280, 1280), (1, 16, 16, 256, 64), (2, 4, 8, 128, 48), (1, 2, 16, 128, 16), (3, 8, 8, 128, 32),
+                                       (1, 12, 12, 1280, 1280), (2, 4, 12, 128, 32)])
 def test_conv_ws_upsample_in_front(ops, b, h, w, c, n):
     """diffusers' Upsample2D: nearest-neighbour 2x, then the 3x3 convolution -- the slab holds the INPUT rows, a tap reads
     pixel (uy >> 1, ux >> 1).  Output maps 16 and 32 wide, both block heights where they apply."""
@@ -115,7 +123,7 @@ def test_conv_ws_upsample_taps_exact(ops):
             assert torch.equal(got, want), (py, px, v)
 
 
-@pytest.mark.parametrize("h,w", [(8, 8), (16, 16), (8, 32)])
+@pytest.mark.parametrize("h,w", [(8, 8), (16, 16), (8, 32), (12, 12), (8, 24)])
 def test_conv_ws_taps_and_borders_exact(ops, h, w):
     """A one-hot pixel through one-hot weights: out[y][x][n] = 1 exactly where (y, x) = pixel - tap offset lies in the map --
     every tap, both borders, every 16-pixel block, each wave's channel quarter (exact in bf16: single products of 1)."""
@@ -166,7 +174,8 @@ def test_conv_ws_rejects_shapes_it_does_not_take(ops):
     from mvd_amd.packing import pack_ws
     w4 = rnd(16, 128, 3, 3)
     wp, bias = pack_ws(w4).cuda(), torch.zeros(16).cuda()
-    for shape, v in [((1, 12, 12, 128), 0), ((1, 64, 64, 128), 0), ((32, 8, 8, 128), 0),      # 12-wide map, 64-wide map, more than 1024 rows
-                     ((1, 32, 32, 128), 2), ((1, 8, 8, 128), 2), ((1, 8, 8, 128), 3)]:        # forms that do not take the width / do not exist
+    for shape, v in [((1, 20, 20, 128), 0), ((1, 64, 64, 128), 0), ((32, 8, 8, 128), 0),      # 20-wide map, 64-wide map, more than 1024 rows
+                     ((1, 6, 12, 128), 0),                                                     # 72 pixels: not whole 48-pixel blocks
+                     ((1, 32, 32, 128), 2), ((1, 8, 8, 128), 2), ((1, 8, 8, 128), 3), ((1, 12, 12, 128), 1), ((1, 8, 8, 128), 4)]:        # forms that do not take the width / do not exist
         with pytest.raises(L.MvdError, match="conv_ws"):
             ops.conv3x3_ws(rnd(*shape).cuda(), wp, bias, 16, variant=v)

@@ -376,6 +376,25 @@ def test_sm_linear_epilogues(ops, tile):
     close(got32, a.float() @ w[:, :k1].float().T + bias, tol=1e-4, what="sm linear fp32 out")
 
 
+def test_sm_splitk_grid_beyond_the_chip_takes_the_nowait_combine(ops):
+    """a forced split whose grid cannot be resident at once (here 16 x 20 tiles x 12 slices = 3840 workgroups of 64 KB
+    LDS) must not let its resident slices poll ~1 ms each for slices that cannot start: the launcher's occupancy hint switches
+    such a launch to the no-wait combine.  Result correct and bit-stable; a grid that fits keeps the rendezvous."""
+    m, n, k = 1024, 1280, 1536
+    a, w = rnd(m, k, seed=1), rnd(n, k, scale=1 / math.sqrt(k), seed=2)
+    bias = rnd(n, seed=3, dtype=torch.float32)
+    want = a.float() @ w.float().T + bias
+    args = (a.cuda(), w.cuda(), bias.cuda())
+    got = ops.linear(*args, force_cfg=100 + 10 * 0 + 4, splitk=12)
+    plan = ops.last_gemm_plan()
+    assert plan["grid"] == 16 * 20 * 12 and plan["nowait"] == 1, plan
+    close(got, want, what="sm linear split 12 beyond the chip")
+    assert torch.equal(got, ops.linear(*args, force_cfg=100 + 10 * 0 + 4, splitk=12))
+    ops.linear(a[:128].cuda(), w[:256].contiguous().cuda(), bias[:256].contiguous().cuda(), force_cfg=100 + 10 * 0 + 4, splitk=4)
+    plan = ops.last_gemm_plan()
+    assert plan["grid"] == 2 * 4 * 4 and plan["nowait"] == 0, plan
+
+
 @pytest.mark.parametrize("splitk", [2, 3, 5, 10])
 @pytest.mark.parametrize("tile", [0, 1, 3, 5, 6])
 def test_sm_splitk_in_kernel_combine(ops, tile, splitk):
