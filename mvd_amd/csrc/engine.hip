@@ -113,6 +113,8 @@ struct mvd_engine {
     rc_keep = h.rc_keep; cam_emb = h.cam_emb; cam_batch = h.cam_batch;
   }
   struct GraphEntry { std::string key; hipGraph_t g; hipGraphExec_t x; HostState after; };
+  bool dual_late = false;                   // set by the main pass once it runs (mostly) alone again: single-stream launch policy
+  int dual_late_from = MVD_ENV_INT("MVD_DUAL_LATE_FROM", 99);   // up-block index from which that holds (99: never)
   bool graph_on = false;
   std::vector<GraphEntry> graphs;
   std::vector<std::string> graph_seen;      // keys that ran once un-captured (first-use initialisation happens there)
@@ -308,13 +310,13 @@ struct Ctx {
     // to 512 of the 128x160 tile (measured on one box, cfg4 cold: 65.6 -> 64.6 -> 63.5 ms per step; halving or dropping the
     // four-way split of the 8x8 level instead: no gain / a loss; profiles/r03_probe_dual_stream_policies.log).
     int fc = -1;
-    if (e->dual_now && !(g_debug_flags & 32) && !g.geglu && !g.ln_c1 && !g.out_f32 && g.N % 320 == 0 && mvd_gemm_pp_applicable(g)) {
+    if (e->dual_now && !e->dual_late && !(g_debug_flags & 32) && !g.geglu && !g.ln_c1 && !g.out_f32 && g.N % 320 == 0 && mvd_gemm_pp_applicable(g)) {
       const int cfg = mvd_gemm_pick_config(g);
       const long t7 = (long)((g.M + 255) / 256) * (g.N / 320);
       if (t7 >= 100) { S = 1; if (cfg != 7) fc = 7; }      // (below 100 tiles -- the 8x8 level -- the heuristic's tile and split stand)
     }
     const size_t mark = e->tmp.off;
-    if (S > 1) { g.splitk = S; g.part = talloc<float>((size_t)S * g.M * g.N); }
+    if (S > 1) { g.splitk = S; g.part = talloc<float>((size_t)S * g.M * g.N); } else g.splitk = 1;   // (decided: 0 = undecided)
     static const bool trace = MVD_ENV_INT("MVD_TRACE_GEMM", 0) != 0;
     if (trace && !dry) fprintf(stderr, "gemm M=%d N=%d K=%d mode=%d nseg=%d geglu=%d cfg=%d splitk=%d\n", g.M, g.N, g.Ktot, g.seg[0].mode, g.nseg, g.geglu, mvd_gemm_pick_config(g), S);
     int r = 0;
@@ -739,6 +741,9 @@ struct UNetPass {
     for (int i = 0; i < n; ++i) {
       const int co = cfg.block_out_channels[n - 1 - i];
       const std::string bk = "up_blocks." + std::to_string(i);
+      // main pass of a two-stream forward: from up block `dual_late_from` on the encoder pass (41 % of the work, ahead by design
+      // and on the higher-priority stream) has normally drained -- launches must fill the chip by themselves again
+      if (!o.capture && i >= c.e->dual_late_from) c.e->dual_late = true;
       for (int j = 0; j <= Lb; ++j) {
         Act skip = skips.back(); skips.pop_back();
         if (skip.H != h.H || skip.W != h.W) { mvd_set_error("up block %d: skip %dx%d vs hidden %dx%d (odd latent size unsupported)", i, skip.H, skip.W, h.H, h.W); return -13; }
@@ -1002,6 +1007,8 @@ int forward_body(mvd_engine* e, const mvd_forward_args_t& a, hipStream_t s, bool
   // levels (cfg4 65.0 -> 63.5 ms, same box).  `dual` (a function of the call's flags only) decides the workspace layout -- in
   // the sizing runs too; whether the side stream is really used also needs: no per-launch profiling.
   const bool dual = use_img && !reuse && !ref_only;
+  e->dual_late = false;
+  if (g_debug_flags & (3 << 19)) e->dual_late_from = (g_debug_flags >> 19) & 3;      // (A/B: debug-flag bits 19-20 = 1..3)
   // (Round 5: under hipGraph capture too.  The fork event is recorded on the capturing stream and waited for by the side stream,
   //  which thereby joins the capture; the per-feature events and the join event become edges of the graph, so a replayed
   //  forward keeps the two-branch schedule instead of serialising the passes.  Debug flag 65536 restores the one-stream capture.)
@@ -1458,6 +1465,7 @@ int mvd_op_linear(const void* a, const void* a2, int k1, int k2, const void* w, 
     if (int r = mvd_launch_gemm(g, (hipStream_t)stream, force_cfg)) return r;
     return mvd_launch_splitk_reduce(g, (hipStream_t)stream);
   }
+  g.splitk = 1;            // the caller DECIDED not to split (0 would mean "undecided": the tile heuristic may then assume a deep split)
   return mvd_launch_gemm(g, (hipStream_t)stream, force_cfg);
 }
 
@@ -1500,6 +1508,7 @@ int mvd_op_conv3x3(const void* x, int batch, int in_h, int in_w, int cin, int st
     if (int r = mvd_launch_gemm(g, (hipStream_t)stream, force_cfg)) return r;
     return mvd_launch_splitk_reduce(g, (hipStream_t)stream);
   }
+  g.splitk = 1;            // the caller DECIDED not to split (0 would mean "undecided": the tile heuristic may then assume a deep split)
   return mvd_launch_gemm(g, (hipStream_t)stream, force_cfg);
 }
 

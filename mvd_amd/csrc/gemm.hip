@@ -586,7 +586,7 @@ static int deep_conv_split(const MvdGemmArgs& a, long t7) {
   static const int on = MVD_ENV_INT("MVD_GEMM_DEEP_CONV_SPLIT", 1);
   // (a.splitk: 0 = undecided, the engine asks mvd_gemm_pick_splitk first; a caller that fixed a shallow split -- the operator entry
   //  points with their default splitk = 1 -- keeps the tile that suits it: 32 unsplit 256x320 tiles would leave 224 CUs idle)
-  if (!on || a.seg[0].mode == MVD_A_DENSE || a.geglu || a.out_f32 || t7 < 24 || t7 > 64 || a.Ktot < 8192 || (a.splitk > 0 && a.splitk < 4)) return 1;
+  if (!on || (mvd_debug_flags() & 262144) || a.seg[0].mode == MVD_A_DENSE || a.geglu || a.out_f32 || t7 < 24 || t7 > 64 || a.Ktot < 8192 || (a.splitk > 0 && a.splitk < 4)) return 1;
   int s = (int)(256 / t7);
   while (s > 1 && a.Ktot / 64 / s < 16) --s;
   return s > 16 ? 16 : s;

@@ -510,7 +510,10 @@ static bool launch_gn_slice(const bf16_t* x0, const bf16_t* x1, int c0, int c1, 
   }
   if (nv < 1 || nv > 21) return false;
   const long slice_bytes = (long)hw * cs * 2, nwg = (long)batch * nslice;
-  if (slice_bytes > 96 * 1024 && nwg < 128) return false;           // few big slices: the two-kernel form has more parallelism
+  // few big slices: the two-kernel form has more parallelism -- but it is two launches.  Round 5 (A/B by debug flag 2097152 = the
+  // old floor of 128): one image's 64x64 map (8 slices of 327 KB) takes the one-pass form as well
+  const long min_wg = (mvd_debug_flags() & 2097152) ? 128 : 8;
+  if (slice_bytes > 96 * 1024 && nwg < min_wg) return false;
   const dim3 grid((unsigned)nwg), blk((unsigned)threads);
 #define GN_SLICE(NVT) hipLaunchKernelGGL(gn_slice_kernel<NVT>, grid, blk, 0, s, x0, x1, c0, c1, batch, hw, groups, gpw, eps, gamma, beta, silu, y)
   if (nv <= 2) GN_SLICE(2); else if (nv <= 4) GN_SLICE(4); else if (nv <= 8) GN_SLICE(8); else if (nv <= 16) GN_SLICE(16); else GN_SLICE(21);

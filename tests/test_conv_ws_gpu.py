@@ -58,7 +58,7 @@ def variants(h, w):
                                        (1, 4, 32, 128, 16), (1, 24, 16, 128, 32),
                                        # round 5: the 12 x 12 and 24 x 24 maps of the reference's 768 x 768 default (96 x 96 latents)
                                        (1, 12, 12, 1280, 1280), (1, 24, 24, 1280, 1280), (2, 12, 12, 256, 48), (1, 8, 24, 128, 32),
-                                       (3, 4, 12, 128, 16), (2, 24, 24, 128, 64)])
+                                       (3, 4, 12, 128, 16), (1, 24, 24, 128, 64), (2, 16, 24, 128, 64)])
 def test_conv_ws_plain_rowvec_residual(ops, b, h, w, c, n):
     from mvd_amd.packing import pack_ws
     x, w4 = rnd(b, h, w, c, seed=1), rnd(n, c, 3, 3, scale=1 / math.sqrt(9 * c), seed=2)

@@ -33,8 +33,12 @@ def main():
     rows = []
     for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "0"), r.get("Grid_Size", "0")))
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "0"), r.get("Grid_Size_X", r.get("Grid_Size", "0"))))
     rows.sort()
+    # the forwards only: from the first launch of the target kernel on (model set-up and weight filling run torch kernels before it)
+    first = next((i for i, r in enumerate(rows) if target in r[2]), 0)
+    first = max(0, first - 40)                      # (the few dozen engine launches in front of a forward's first attention)
+    rows = rows[first:]
     if not rows:
         print("no kernel trace rows found under", d)
         return
@@ -65,6 +69,38 @@ def main():
         stats[grid][dom].append(dur / 1e3)
         for k, v in ov.items():
             share[k] += v
+    # ---- timeline: how long does each queue run alone, and what does the main queue run while the side queue is idle?
+    main_q = max(queues, key=queues.get)
+    side = sorted((s, e) for (s, e, _, q, _) in rows if q != main_q)
+    merged = []
+    for s_, e_ in side:
+        if merged and s_ <= merged[-1][1]:
+            merged[-1][1] = max(merged[-1][1], e_)
+        else:
+            merged.append([s_, e_])
+    t0, t1 = rows[0][0], max(r[1] for r in rows)
+    side_busy = sum(e_ - s_ for s_, e_ in merged)
+    print(f"# wall {1e-6 * (t1 - t0):.2f} ms; side queue(s) busy {100 * side_busy / (t1 - t0):.1f} % of it")
+    import bisect
+    starts = [m[0] for m in merged]
+    alone = collections.defaultdict(lambda: [0, 0, 0])      # (kernel, workgroups) -> [launches, ns alone, ns total]
+    for (s_, e_, name, q, grid) in rows:
+        if q != main_q:
+            continue
+        i = bisect.bisect_right(starts, s_) - 1
+        ov = 0
+        for j in range(max(i, 0), len(merged)):
+            if merged[j][0] >= e_:
+                break
+            ov += max(0, min(e_, merged[j][1]) - max(s_, merged[j][0]))
+        short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:44]
+        rec = alone[(short, grid)]
+        rec[0] += 1; rec[1] += (e_ - s_) - ov; rec[2] += e_ - s_
+    tot_alone = sum(v[1] for v in alone.values())
+    print(f"# main-queue kernel time with the side queue idle: {1e-6 * tot_alone:.2f} ms of {1e-6 * sum(v[2] for v in alone.values()):.2f} ms; the largest items "
+          "(kernel, grid size in work-items = workgroups x threads): launches, ms alone, share of that kernel's own time")
+    for (k, g), v in sorted(alone.items(), key=lambda kv: -kv[1][1])[:28]:
+        print(f"   {k:44s} grid {g:>9s}  launches {v[0]:4d}  alone {1e-6 * v[1]:7.3f} ms  ({100 * v[1] / max(v[2], 1):5.1f} % of its time)")
     tot = sum(share.values())
     print("# share of the attention kernel's lifetime by what the other queue was running: " +
           ", ".join(f"{k} {100 * v / tot:.1f} %" for k, v in share.most_common()))
