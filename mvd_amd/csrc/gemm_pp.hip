@@ -212,6 +212,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const MvdGemmArgs a) {
     if (HAS_CONV && (AMODE != 2 || lk < nkt_conv)) {
       // K order [channel slice][tap][64 channels] (gemm.hip): slice = lk / 9, tap = lk % 9
       const int sl = lk / 9, tap = lk - sl * 9;
+#ifdef PP_ABLATE_A_TAPS   // round-5 timing-only ablation (WRONG RESULTS): the A operand is fetched for tap 0 of every 64-channel slice only --
+      if (tap != 0) return;   // what an activation patch held in LDS across its nine taps could save at most
+#endif
       const int dy = tap / 3, dx = tap - dy * 3;
       unsigned soff = (unsigned)(sl * 128);
       if (!conv_ups) soff += (unsigned)(dy * conv_rowB + dx * conv_c2);

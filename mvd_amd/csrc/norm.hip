@@ -510,9 +510,10 @@ static bool launch_gn_slice(const bf16_t* x0, const bf16_t* x1, int c0, int c1, 
   }
   if (nv < 1 || nv > 21) return false;
   const long slice_bytes = (long)hw * cs * 2, nwg = (long)batch * nslice;
-  // few big slices: the two-kernel form has more parallelism -- but it is two launches.  Round 5 (A/B by debug flag 2097152 = the
-  // old floor of 128): one image's 64x64 map (8 slices of 327 KB) takes the one-pass form as well
-  const long min_wg = (mvd_debug_flags() & 2097152) ? 128 : 8;
+  // few big slices: the two-kernel form has more parallelism.  (Round 5 re-measured the one-pass form for one image's 64x64 map --
+  // 8 slices of 327 KB, 13 launches fewer per pass: debug flag 2097152 -- on one box, three alternations: cfg2 4.27 -> 4.39 ms,
+  // cfg3 cold 6.50 -> 6.61 ms.  Fewer launches, more time: the floor stays.)
+  const long min_wg = (mvd_debug_flags() & 2097152) ? 8 : 128;
   if (slice_bytes > 96 * 1024 && nwg < min_wg) return false;
   const dim3 grid((unsigned)nwg), blk((unsigned)threads);
 #define GN_SLICE(NVT) hipLaunchKernelGGL(gn_slice_kernel<NVT>, grid, blk, 0, s, x0, x1, c0, c1, batch, hw, groups, gpw, eps, gamma, beta, silu, y)
