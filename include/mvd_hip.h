@@ -212,6 +212,10 @@ int mvd_op_nchw_to_nhwc(const float* x, int batch, int c, int hw, const float* s
                         void* stream);
 int mvd_op_nhwc_to_nchw(const void* x, int batch, int hw, int c, float* y, void* stream);
 int mvd_op_f32_to_bf16(const float* x, int64_t n, void* y, void* stream);
+/* One fp32 linear layer of the camera / time MLPs (camera_encoder.py:31-85; diffusers TimestepEmbedding): y[b][o] =
+ * sum_k act(x[b][k]) W[o][k] + bias[o]; W fp32 [n][k], or bf16 with wbf16 = 1; act_in = 1 applies SiLU to the inputs. */
+int mvd_op_skinny_linear(const float* x, int ldx, int batch, int k, const void* w, int wbf16, const float* bias, int n, int act_in,
+                         float* y, int ldy, void* stream);
 int mvd_gemm_num_configs(void);
 /* What the calling thread's last GEMM/conv launch did: out[5] = {tile config, split-K, work items, workgroups, workgroups
  * per CU}; last attention launch: out[2] = {waves per workgroup, workgroups}.  Parity tests assert with these that the

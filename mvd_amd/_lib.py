@@ -99,6 +99,8 @@ _SIGS = {
     "mvd_op_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mvd_op_nhwc_to_nchw": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mvd_op_f32_to_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "mvd_op_skinny_linear": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_int, C.c_void_p]),
     "mvd_gemm_num_configs": (C.c_int, []),
     "mvd_debug_last_gemm_plan": (C.c_int, [C.POINTER(C.c_int)]),
     "mvd_debug_last_gemm_nowait": (C.c_int, []),

@@ -1013,16 +1013,41 @@ int forward_body(mvd_engine* e, const mvd_forward_args_t& a, hipStream_t s, bool
   //  which thereby joins the capture; the per-feature events and the join event become edges of the graph, so a replayed
   //  forward keeps the two-branch schedule instead of serialising the passes.  Debug flag 65536 restores the one-stream capture.)
   e->dual_now = dual && !dry && !(e->graph_on && (g_debug_flags & 65536)) && (!e->prof || e->prof_overlap) && !(g_debug_flags & 16);
-  if (e->dual_now) {   // fork in front of everything else: the encoder pass needs nothing of the camera path
+  // Where the side stream forks: in front of everything (the encoder pass needs nothing of the camera path).  Round 5's two-stream
+  // kernel stats showed what that does to the ~30 latency-bound launches in front of the main pass (camera MLPs, time MLPs): the
+  // encoder's persistent 256-workgroup kernels fill every CU's register file, so a small kernel of the other stream waits for
+  // a whole big kernel to retire -- 145 us per time-MLP launch, 390 us for the grouped modulator layer, ~1.6 ms before the main
+  // pass (the step's critical path) can start.  The alternative `early` (debug flag 4194304: those launches of BOTH passes first,
+  // on an otherwise idle chip, the fork behind them) was measured and LOSES: cfg4 60.19 -> 60.96 ms, cfg3 6.46 -> 6.67 ms (three /
+  // two same-box alternations) -- an idle chip for 0.75 ms costs more than the slowed-down front matter.  What helped instead is
+  // making those launches cheap (misc.hip skinny_mfma_kernel).  `early` is a function of the call's flags only, so the sizing run
+  // allocates in the same order.
+  const bool early = dual && (g_debug_flags & 4194304);
+  auto fork = [&]() -> int {
+    if (!e->dual_now) return 0;
     CHECK(e->ensure_side_stream());
     if (hipEventRecord(e->fork_ev, s) != hipSuccess || hipStreamWaitEvent(e->side, e->fork_ev, 0) != hipSuccess) { mvd_set_error("forward: stream fork failed"); return -3; }
-  }
+    return 0;
+  };
+  if (!early) CHECK(fork());
 
   // ---- camera path (fp32) -> embedding + FiLM scale/shift per modulator
   std::unordered_map<std::string, std::pair<float*, float*>> film_ss;
   // (running this path on a side stream concurrently with the reference pass was measured: +0.1 %, within noise --
   //  the persistent GEMMs leave no free CU resources for it -- so it stays on the caller's stream)
   if (use_cam) CHECK(camera_path(c, a, film_ss));
+  const float* tproj_main = nullptr;
+  const float* tproj_enc = nullptr;
+  if (early) {
+    c.set = 0;
+    CHECK(time_path(c, a.timesteps, B, &tproj_main));
+    c.set = e->share_encoder ? 0 : 1;
+    float* tz = c.aalloc<float>(a.ref_batch);
+    if (!dry) CHECK((int)hipMemsetAsync(tz, 0, a.ref_batch * sizeof(float), s));
+    CHECK(time_path(c, tz, a.ref_batch, &tproj_enc));
+    c.set = 0;
+    CHECK(fork());
+  }
 
   // ---- reference image encoder pass (frozen UNet at t = 0, plain attention) -> adapter K/V
   // Small batches: on the side stream, concurrently with the main pass (see mvd_engine::side).  Not under graph capture /
@@ -1035,10 +1060,12 @@ int forward_body(mvd_engine* e, const mvd_forward_args_t& a, hipStream_t s, bool
     if (e->dual_now) { c.s = e->side; c.nowait = true; }
     c.set = e->share_encoder ? 0 : 1;
     const int Br = a.ref_batch;
-    float* tz = c.talloc<float>(Br);
-    if (!dry) CHECK((int)hipMemsetAsync(tz, 0, Br * sizeof(float), c.s));
-    const float* tproj = nullptr;
-    CHECK(time_path(c, tz, Br, &tproj));
+    const float* tproj = tproj_enc;
+    if (!tproj) {
+      float* tz = c.talloc<float>(Br);
+      if (!dry) CHECK((int)hipMemsetAsync(tz, 0, Br * sizeof(float), c.s));
+      CHECK(time_path(c, tz, Br, &tproj));
+    }
     bf16_t* tx = c.aalloc<bf16_t>((size_t)Br * L * xd);
     Act xin = c.new_act(Br, H, Wd, 64, true);   // im2col rows for conv_in
     if (!dry && !c.err) {
@@ -1069,8 +1096,8 @@ int forward_body(mvd_engine* e, const mvd_forward_args_t& a, hipStream_t s, bool
 
   // ---- main pass
   c.set = 0;
-  const float* tproj = nullptr;
-  CHECK(time_path(c, a.timesteps, B, &tproj));
+  const float* tproj = tproj_main;
+  if (!tproj) CHECK(time_path(c, a.timesteps, B, &tproj));
   bf16_t* tx = c.aalloc<bf16_t>((size_t)B * L * xd);
   Act xin = c.new_act(B, H, Wd, 64, true);   // im2col rows for conv_in
   if (!dry && !c.err) {
@@ -1571,6 +1598,12 @@ int mvd_op_nhwc_to_nchw(const void* x, int batch, int hw, int c, float* y, void*
 }
 int mvd_op_f32_to_bf16(const float* x, int64_t n, void* y, void* stream) {
   return mvd_launch_f32_to_bf16(x, n, (bf16_t*)y, (hipStream_t)stream);
+}
+// the fp32 linear layer of the camera / time MLPs: y[b][o] = sum_k act(x[b][k]) W[o][k] + bias[o]  (W fp32, or bf16 with wbf16 = 1;
+// act_in = 1: SiLU on the inputs)
+int mvd_op_skinny_linear(const float* x, int ldx, int batch, int k, const void* w, int wbf16, const float* bias, int n, int act_in,
+                         float* y, int ldy, void* stream) {
+  return mvd_launch_skinny_linear(x, ldx, batch, k, w, wbf16, bias, n, act_in, y, ldy, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -258,6 +258,83 @@ __global__ __launch_bounds__(256) void skinny_linear_vec_kernel(const float* __r
   }
 }
 
+// Matrix-pipe form (round 5): y[b][o] = sum_k act(x[b][k]) * W[o][k] + bias[o] in FULL fp32 (v_mfma_f32_32x32x2_f32: the camera
+// path stays fp32, Q9) for the camera / time MLPs of the front matter -- ~30 launches in front of the main pass, on the step's
+// critical path.  The vector form above gives a wave 2 features x 32 rows (it works on 32 rows whatever the batch is), reloads
+// every x element per feature pair and ends in 64 six-step wave reductions: 150 us alone for the grouped modulator layer
+// (14088 x 512 weights, 32 rows), 390 us beside the encoder pass's persistent kernels.
+// Here a workgroup owns 32 output features x 32 batch rows; its four waves split K (wave w takes the 8-float chunks c = w mod 4;
+// 16 bf16 for WBF16) and are summed through LDS in wave order (bit-deterministic).  MFMA operands: A = W (row = feature),
+// B = x^T (column = batch row): lane l supplies W[o0 + (l & 31)][k] and x[b0 + (l & 31)][k] for k = chunk + 4 (l >> 5) + t,
+// t = 0..3, i.e. ONE 16-byte load per operand and lane feeds four MFMAs (any pairing of k values is a valid contraction as long
+// as A and B agree).  D: lane (j = l & 31, h = l >> 5) holds features o0 + 8 q + 4 h + (r & 3), q = r >> 2, of batch row b0 + j.
+// GROUPED as above (a tile's 32 features must share a segment: the launcher checks that segment ends are multiples of 32).
+template <bool WBF16, bool GROUPED>
+__global__ __launch_bounds__(256) void skinny_mfma_kernel(const float* __restrict__ x, int ldx, int batch, int k,
+                                                           const void* __restrict__ wv, const float* __restrict__ bias, int n, int act_in,
+                                                           float* __restrict__ y, int ldy, const MvdSegTable seg, int xseg) {
+  typedef __attribute__((ext_vector_type(16))) float f32x16;
+  __shared__ f32x16 red[3][64];
+  constexpr int KS = WBF16 ? 16 : 8;                 // k elements a wave consumes per iteration (both lane halves together)
+  constexpr int KL = KS / 2;                         // per lane
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int o0 = blockIdx.x * 32;
+  if constexpr (GROUPED) {
+    int g = 0;
+    while (g + 1 < seg.n && o0 >= seg.end[g]) ++g;
+    x += (size_t)g * xseg;
+  }
+  const int o = o0 + li < n ? o0 + li : n - 1;       // features past n repeat the last one (never stored)
+  for (int b0 = 0; b0 < batch; b0 += 32) {
+    const int jr = b0 + li < batch ? b0 + li : batch - 1;
+    const float* xr = x + (size_t)jr * ldx;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 4
+    for (int kk = wave * KS + h * KL; kk < k; kk += 4 * KS) {
+      float wf[KL], xf[KL];
+      if constexpr (WBF16) {
+        const u32x4 r = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(wv) + (size_t)o * k + kk);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { wf[2 * e] = bflo(r[e]); wf[2 * e + 1] = bfhi(r[e]); }
+      } else {
+        const f32x4 r = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(wv) + (size_t)o * k + kk);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wf[e] = r[e];
+      }
+#pragma unroll
+      for (int q = 0; q < KL / 4; ++q) {
+        const f32x4 x4 = *reinterpret_cast<const f32x4*>(xr + kk + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xf[4 * q + e] = act_in == 1 ? silu_f(x4[e]) : x4[e];
+      }
+#pragma unroll
+      for (int e = 0; e < KL; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[e], xf[e], acc, 0, 0, 0);
+    }
+    if (wave) red[wave - 1][lane] = acc;
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int w = 0; w < 3; ++w) {
+        const f32x16 t = red[w][lane];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += t[r];
+      }
+      if (b0 + li < batch) {
+        float* yr = y + (size_t)(b0 + li) * ldy;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int oo = o0 + 8 * (r >> 2) + 4 * h + (r & 3);
+          if (oo < n) yr[oo] = acc[r] + (bias ? bias[oo] : 0.f);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 __global__ void timestep_embedding_kernel(const float* __restrict__ t, int dim, float* __restrict__ y) {
   const int b = blockIdx.x;
   const int half = dim >> 1;
@@ -486,6 +563,16 @@ int mvd_launch_skinny_linear(const float* x, int ldx, int batch, int k, const vo
   const int kv = wbf16 ? 8 : 4;
   const bool vec = (k % kv) == 0 && (ldx % 4) == 0 && (((uintptr_t)x | (uintptr_t)w) & 15) == 0;
   static const int use_vec = MVD_ENV_INT("MVD_SKINNY_VEC", 1);
+  // the matrix-pipe form from 8 rows up (debug flag 8388608: the vector form everywhere, A/B).  Measured, same box: alone (one
+  // stream) the 32-row front matter of a forward drops from ~0.75 to ~0.35 ms; beside the encoder pass a launch's time is the wait
+  // for a CU whose register file a persistent kernel has filled (grouped layer 389 -> 81 us, time MLPs 145 -> 70 us in situ) and the
+  // two-stream step gains nothing measurable (60.85 -> 60.72 ms, noise); at one row the vector form is 0.6 % of a cfg3 step faster
+  if (vec && batch >= 8 && !(mvd_debug_flags() & 8388608)) {
+    const MvdSegTable none{};
+    if (wbf16) hipLaunchKernelGGL((skinny_mfma_kernel<true, false>), dim3(nblk(n, 32)), dim3(256), 0, s, x, ldx, batch, k, w, bias, n, act_in, y, ldy, none, 0);
+    else hipLaunchKernelGGL((skinny_mfma_kernel<false, false>), dim3(nblk(n, 32)), dim3(256), 0, s, x, ldx, batch, k, w, bias, n, act_in, y, ldy, none, 0);
+    return check("skinny_mfma");
+  }
   if (vec && use_vec) {
     constexpr int F = 2;
     const dim3 g(nblk(n, 4 * F));
@@ -503,6 +590,12 @@ int mvd_launch_skinny_linear_grouped(const float* x, int ldx, int xseg, int batc
   if (!x || !w || !y || batch <= 0 || batch > 4096 || k <= 0 || (k % 4) || (ldx % 4) || n <= 0 || ldy < n || seg.n < 1 || seg.n > 16 ||
       seg.end[seg.n - 1] != n || (((uintptr_t)x | (uintptr_t)w) & 15) || (xseg % 4)) { mvd_set_error("skinny_linear_grouped: bad arguments"); return -1; }
   for (int g = 0; g < seg.n; ++g) if (seg.end[g] % 2) { mvd_set_error("skinny_linear_grouped: segment ends must be even"); return -1; }
+  bool tiles_ok = batch >= 8 && !(mvd_debug_flags() & 8388608);    // a 32-feature tile must not straddle two segments
+  for (int g = 0; g + 1 < seg.n; ++g) tiles_ok = tiles_ok && seg.end[g] % 32 == 0;
+  if (tiles_ok) {
+    hipLaunchKernelGGL((skinny_mfma_kernel<false, true>), dim3(nblk(n, 32)), dim3(256), 0, s, x, ldx, batch, k, (const void*)w, bias, n, 0, y, ldy, seg, xseg);
+    return check("skinny_mfma_grouped");
+  }
   hipLaunchKernelGGL((skinny_linear_vec_kernel<false, 2, true>), dim3(nblk(n, 8)), dim3(256), 0, s, x, ldx, batch, k, (const void*)w, bias, n, 0, y, ldy, seg, xseg);
   return check("skinny_linear_grouped");
 }

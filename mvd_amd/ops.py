@@ -210,6 +210,17 @@ def cfg_combine(uncond_cond, guidance_scale):
     return out
 
 
+def skinny_linear(x, w, bias=None, silu_in=False):
+    """fp32 linear layer of the camera / time MLPs: x (B, K) fp32, w (N, K) fp32 or bf16 -> (B, N) fp32."""
+    assert x.dtype == torch.float32 and x.is_cuda and x.dim() == 2 and w.dim() == 2 and w.shape[1] == x.shape[1]
+    assert w.dtype in (torch.float32, torch.bfloat16) and x.is_contiguous() and w.is_contiguous()
+    b, k = x.shape
+    n = w.shape[0]
+    y = torch.empty(b, n, device=x.device, dtype=torch.float32)
+    L.call("mvd_op_skinny_linear", _p(x), k, b, k, _p(w), int(w.dtype == torch.bfloat16), _p(bias), n, int(silu_in), _p(y), n, _s())
+    return y
+
+
 def nchw_to_nhwc(x, scale=None, shift=None):
     B, c, H, W = x.shape
     y = torch.empty(B, H, W, c, device=x.device, dtype=torch.bfloat16)

@@ -591,3 +591,31 @@ def test_attention_split_kv(ops, B, heads, nq, nk, nsplit, shift):
     close(got, want.transpose(1, 2).reshape(B, nq, C), tol=2 ** -6, what=f"split-KV attention {B}x{heads}x{nq}x{nk} / {nsplit}")
     for _ in range(4):
         assert torch.equal(got, ops.attention_split(qc, kc, vc, heads, nsplit)), "split-KV merge is not bit-deterministic"
+
+
+@pytest.mark.parametrize("batch", [1, 8, 11, 32, 40])
+@pytest.mark.parametrize("k,n,wbf16,silu", [(1020, 1024, False, False), (512, 1000, False, True), (2048, 1024, False, False),
+                                            (320, 1280, True, False), (1280, 1280, True, True), (512, 14088, False, False)])
+def test_skinny_linear_matrix_pipe_form(ops, batch, k, n, wbf16, silu):
+    """Round 5: the camera / time MLP layers on the fp32 matrix pipe (misc.hip skinny_mfma_kernel): every layer shape of the front
+    matter (Fourier projection K = 1020, the 2048-wide concat layer, the time MLPs with bf16 weights, the 14088-wide modulator
+    layer), batches of 1 (the vector form: the matrix-pipe form starts at 8 rows) / 8 / 11 / 32 / 40 rows (ragged tiles, two tiles), N not a multiple of the 32-feature tile, SiLU on the
+    inputs -- against torch fp64, and bit-identical run to run; the vector form (debug flag 8388608) agrees within fp32 rounding."""
+    from mvd_amd import _lib as L
+    g = torch.Generator().manual_seed(batch * 7 + k + n)
+    x = torch.randn(batch, k, generator=g)
+    w = (torch.randn(n, k, generator=g) / math.sqrt(k))
+    w = w.to(torch.bfloat16) if wbf16 else w
+    bias = torch.randn(n, generator=g)
+    xin = F.silu(x.double()) if silu else x.double()
+    want = (xin @ w.double().T + bias.double()).float()
+    got = ops.skinny_linear(x.cuda(), w.cuda(), bias.cuda(), silu_in=silu)
+    err = (got.cpu() - want).abs().max().item()
+    assert err <= 2e-5 * max(1.0, want.abs().max().item()), err
+    assert torch.equal(got, ops.skinny_linear(x.cuda(), w.cuda(), bias.cuda(), silu_in=silu))
+    L.lib().mvd_debug_set_flags(8388608)
+    try:
+        old = ops.skinny_linear(x.cuda(), w.cuda(), bias.cuda(), silu_in=silu)
+    finally:
+        L.lib().mvd_debug_set_flags(0)
+    assert (old - got).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
