@@ -376,6 +376,11 @@ def main():
                          "to_q / to_q_ref scaled by --attn-q-scale so that a row's 8 largest probabilities hold > 90 %% of the mass, as in a "
                          "trained checkpoint -- the attention kernel's clock and rate depend on the operand statistics")
     ap.add_argument("--attn-q-scale", type=float, default=8.0, help="--attn-stats peaked: factor on the query projections")
+    ap.add_argument("--encoder-weights", choices=["distinct", "frozen-copy"], default="distinct",
+                    help="distinct (default, every round's line): the image encoder gets its own random weights -- two packed weight sets, "
+                         "3.96 GB; frozen-copy: image_encoder.unet = a copy of base_unet, what the reference's default training config "
+                         "produces (train_denoising_unet false: both are the frozen pretrained SD-2.1 UNet, training.py:60-65, "
+                         "config/train_config.yaml:43) -- the engine then keeps ONE packed set for both passes (2.0 GB to broadcast)")
     ap.add_argument("--attn-nw", type=int, default=-1, help="measurement: force log2(waves per attention workgroup)")
     ap.add_argument("--debug-flags", type=int, default=0, help="measurement: mvd_debug_set_flags bits")
     ap.add_argument("--launch-dry-run", action="store_true",
@@ -440,7 +445,8 @@ def main():
     # (dedup_encoder_weights=False: the synthetic image-encoder weights differ from the base UNet's, as a trained checkpoint's
     #  do -- and the all-zero placeholders of ranks > 0 must not be "de-duplicated" into a different arena layout than rank 0's)
     model = MultiViewUNet(None, unet_config=UNetConfig.sd21(), init="empty", img_ref_scale=0.3,
-                          cam_modulation_strength=0.2, cache_reference=args.cached, dedup_encoder_weights=False,
+                          cam_modulation_strength=0.2, cache_reference=args.cached,
+                          dedup_encoder_weights="auto" if args.encoder_weights == "frozen-copy" else False,
                           small_batch_twins=pairs < LEAN_PACKING_FROM_PAIRS).to(dev)
     model.eval()
     model.use_hip_graph = args.graph
@@ -449,6 +455,12 @@ def main():
     q_scale = args.attn_q_scale if args.attn_stats == "peaked" else 1.0
     if rank == 0:
         fill_synthetic_weights(model, 0, q_scale)
+        if args.encoder_weights == "frozen-copy" and model.image_encoder is not None:
+            with torch.no_grad():
+                base = dict(model.base_unet.named_parameters())
+                for name, p in model.image_encoder.unet.named_parameters():
+                    p.copy_(base[name])
+            model.mark_weights_changed()
     else:
         with torch.no_grad():
             for p in model.parameters():
@@ -585,7 +597,9 @@ def main():
             "config": {"workload": f"{args.workload}: {desc}", "pairs_per_gpu": pairs, "global_pairs": total_pairs,
                        "latent": f"{args.latent}x{args.latent}x4", "image": f"{8 * args.latent}x{8 * args.latent}", "text_tokens": 77, "forward": forward_kind, "hip_graph": bool(args.graph), "q2_statistics": "global" if args.global_ref_stats else "replica-local",
                        "gflop_per_pair": round(flops_pair / 1e9, 2), "parallelism": f"dp{world} (pairs sharded by object)",
-                       "weights": "synthetic seeded, SD2.1 shapes (865.9M UNet x2 + 99.2M adapter + 19.1M camera)",
+                       "weights": "synthetic seeded, SD2.1 shapes (865.9M UNet x2 + 99.2M adapter + 19.1M camera)" if args.encoder_weights == "distinct"
+                       else "synthetic seeded, SD2.1 shapes; image_encoder.unet = a frozen copy of base_unet (one packed weight set for both passes)",
+                       "encoder_weights": args.encoder_weights, "encoder_weights_shared": bool(getattr(model, "encoder_weights_shared", False)),
                        "attn_stats": {"mode": args.attn_stats, **softmax_stats_proxy(q_scale)}},
             "roofline": roofline, "cpu_baseline": cpu, "output_check": check, "kernel_src_sha": kernel_source_sha(),
             "gpu_ms_per_step_events": round(gpu_ms / args.steps, 3),
