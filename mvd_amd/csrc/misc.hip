@@ -292,17 +292,21 @@ __global__ __launch_bounds__(256) void skinny_mfma_kernel(const float* __restric
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // (the trip count is WAVE-UNIFORM: an MFMA must not sit in a branch only half of the lanes take.  At K = 1020 the upper lane half
+    //  has no last half chunk: such lanes re-load the lower half's chunk and multiply it by zero weights.)
 #pragma unroll 4
-    for (int kk = wave * KS + h * KL; kk < k; kk += 4 * KS) {
+    for (int kc = wave * KS; kc < k; kc += 4 * KS) {
+      const bool live = kc + h * KL < k;
+      const int kk = live ? kc + h * KL : kc;
       float wf[KL], xf[KL];
       if constexpr (WBF16) {
         const u32x4 r = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(wv) + (size_t)o * k + kk);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { wf[2 * e] = bflo(r[e]); wf[2 * e + 1] = bfhi(r[e]); }
+        for (int e = 0; e < 4; ++e) { wf[2 * e] = live ? bflo(r[e]) : 0.f; wf[2 * e + 1] = live ? bfhi(r[e]) : 0.f; }
       } else {
         const f32x4 r = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(wv) + (size_t)o * k + kk);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) wf[e] = r[e];
+        for (int e = 0; e < 4; ++e) wf[e] = live ? r[e] : 0.f;
       }
 #pragma unroll
       for (int q = 0; q < KL / 4; ++q) {
