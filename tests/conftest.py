@@ -73,7 +73,9 @@ def pytest_sessionfinish(session, exitstatus):
     sel = getattr(session.config, "_mvd_selected", set())
     if getattr(session, "shouldstop", False) or getattr(session, "shouldfail", False):
         return                                   # -x stopped the session at an earlier failure: that failure is the verdict
-    bad = missing_headline_tests(sel, _OUTCOMES, torch.cuda.is_available())
+    # (MVD_ASSUME_GPU_SESSION=1: the CPU suite's own check of this hook -- a session in which every headline test skips must fail)
+    have_gpu = torch.cuda.is_available() or os.environ.get("MVD_ASSUME_GPU_SESSION") == "1"
+    bad = missing_headline_tests(sel, _OUTCOMES, have_gpu)
     if bad:
         tr = session.config.pluginmanager.get_plugin("terminalreporter")
         msg = "headline parity tests that did not pass in this GPU session:\n  " + "\n  ".join(bad)

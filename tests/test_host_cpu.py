@@ -226,6 +226,24 @@ def test_headline_parity_tests_cannot_drop_out_of_a_gpu_session():
         assert "pytest.skip(\"needs a GPU\")" in src or "pytest.skip" not in src, t   # the only skip left: no GPU at all
 
 
+def test_a_gpu_session_whose_headline_tests_skip_exits_nonzero():
+    """The hook end to end: a real pytest session that collects the six headline tests and sees them SKIP (there is no GPU here;
+    MVD_ASSUME_GPU_SESSION=1 stands in for one) must end with a non-zero exit status and name the tests; the same selection
+    without the stand-in is an ordinary CPU session and passes."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "pytest", "tests/test_engine_gpu.py", "tests/test_cfg4_shapes_gpu.py", "-m", "gpu", "-q", "-k", "sd21_full_size",
+           "-p", "no:cacheprovider"]
+    env = {**os.environ, "MVD_ASSUME_GPU_SESSION": "1"}
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=root, env=env, timeout=600)
+    assert r.returncode == 1, (r.returncode, r.stdout[-1500:])
+    assert "configs[1..3] parity is not optional" in r.stdout and "test_sd21_full_size_parity_b32: skipped" in r.stdout, r.stdout[-1500:]
+    env.pop("MVD_ASSUME_GPU_SESSION")
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=root, env=env, timeout=600)
+    assert r.returncode == 0, (r.returncode, r.stdout[-1500:])
+
+
 def test_oracle_host_threads_respects_the_cgroup_quota(monkeypatch):
     """oracle.host_threads: torch's default, capped by the affinity mask and by the cgroup CPU quota (cpu.max "1600000 100000" =
     16 cores on the GPU boxes, where torch defaults to 128 threads and the oracle then runs 3.9x slower)."""
