@@ -168,8 +168,11 @@ def test_sd21_batch1_two_stream_forward_is_bit_deterministic():
         pytest.skip("needs a GPU")
     from tests.parity_util import make_inputs, shared_pair
     ocfg, _, model = shared_pair("sd21")
-    for batch, cond in ((1, True), (2, True), (1, False)):
-        inp = make_inputs(ocfg, batch, 64, 77, 5, 1024)
+    # (round 5: also on 96 x 96 latents -- the 12- / 24-wide forms of the weight-streaming convolution inside the two-stream forward,
+    #  and the hipGraph replay whose capture now holds both branches)
+    for batch, cond, hw, graph in ((1, True, 64, False), (2, True, 64, False), (1, False, 64, False), (1, True, 96, False), (1, True, 64, True)):
+        inp = make_inputs(ocfg, batch, hw, 77, 5, 1024)
+        model.use_hip_graph = graph
         model.fourier_projection = inp["proj"].cuda()
         kw = dict(source_camera=inp["src"].cuda(), target_camera=inp["tgt"].cuda(), source_image_latents=inp["lat"].cuda()) if cond else {}
         outs = []
@@ -178,8 +181,10 @@ def test_sd21_batch1_two_stream_forward_is_bit_deterministic():
                 outs.append(model(inp["sample"].cuda(), torch.tensor(400), inp["text"].cuda(), **kw).sample.clone())
         torch.cuda.synchronize()
         assert torch.isfinite(outs[0]).all()
+        model.use_hip_graph = False
         for i in range(1, 6):
-            assert torch.equal(outs[0], outs[i]), f"batch {batch} conditioning {cond}: forward {i} differs from forward 0 in {int((outs[0] != outs[i]).sum())} elements"
+            assert torch.equal(outs[0], outs[i]), (f"batch {batch} conditioning {cond} latent {hw} graph {graph}: forward {i} differs from "
+                                                   f"forward 0 in {int((outs[0] != outs[i]).sum())} elements")
 
 
 def test_sd21_full_size_parity_base_unet_only():
