@@ -24,7 +24,7 @@ def bracket(fn, warm, iters=9):
 
 EMPTY = bracket(lambda: None, [])
 print(f"empty bracket {EMPTY:.2f} us")
-for (B, heads, n) in [(1, 5, 4096), (1, 10, 1024), (1, 20, 256), (2, 5, 4096), (1, 5, 9216)]:
+for (B, heads, n) in [(1, 5, 4096), (1, 10, 1024), (1, 20, 256), (2, 5, 4096), (1, 5, 9216), (2, 5, 9216), (1, 10, 2304), (2, 10, 2304)]:
     C = heads * 64
     qkv = (torch.randn(B, n, 3 * C, device=dev) * 0.5).to(torch.bfloat16)
     q, k, v = qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:]
