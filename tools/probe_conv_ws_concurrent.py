@@ -17,7 +17,10 @@ flush = torch.empty(64 * 1024 * 1024, device=dev, dtype=torch.float32).normal_()
 for name, hw, cin, n, s0, s1 in (("32x32 640->640", 32, 640, 640, 0, 0), ("32x32 640->640 + sc 640", 32, 640, 640, 640, 0),
                                  ("32x32 640->640 + sc 1280|640", 32, 640, 640, 1280, 640), ("32x32 640->640 + sc 640|640", 32, 640, 640, 640, 640),
                                  ("16x16 1280->1280 + sc 1280|1280", 16, 1280, 1280, 1280, 1280), ("8x8 1280->1280 + sc 1280|1280", 8, 1280, 1280, 1280, 1280),
-                                 ("16x16 1280->1280", 16, 1280, 1280, 0, 0)):
+                                 ("16x16 1280->1280", 16, 1280, 1280, 0, 0),
+                                 # round 5: the 12- / 24-wide forms (96 x 96 latents)
+                                 ("24x24 1280->1280", 24, 1280, 1280, 0, 0), ("24x24 1280->1280 + sc 1280|1280", 24, 1280, 1280, 1280, 1280),
+                                 ("12x12 1280->1280", 12, 1280, 1280, 0, 0), ("12x12 1280->1280 + sc 1280|1280", 12, 1280, 1280, 1280, 1280))[int(os.environ.get("FROM", "0")):]:
     x = rnd(1, hw, hw, cin)
     w4 = (torch.randn(n, cin, 3, 3, generator=g) / math.sqrt(9 * cin)).to(torch.bfloat16)
     sc = s0 + s1
@@ -28,7 +31,6 @@ for name, hw, cin, n, s0, s1 in (("32x32 640->640", 32, 640, 640, 0, 0), ("32x32
     wp = pack_ws(w4, wsc).to(dev)
     run = lambda: ops.conv3x3_ws(x, wp, bias, n, shortcut=a0, shortcut2=a1)   # noqa: E731
     first = run().clone()
-    first2 = run2().clone() if False else None
     torch.cuda.synchronize()
     # a second conv_ws problem of its own for the other stream
     x2 = rnd(1, hw, hw, cin); wp2 = wp.clone(); a02 = rnd(1, hw, hw, s0) if s0 else None; a12 = rnd(1, hw, hw, s1) if s1 else None
