@@ -43,6 +43,7 @@ MUST_PASS_ON_GPU = (
     "tests/test_engine_gpu.py::test_sd21_full_size_parity_768",                 # the reference's default image size
     "tests/test_engine_gpu.py::test_sd21_full_size_denoise_loop_cfg",           # chained forwards under CFG (Q4)
     "tests/test_engine_gpu.py::test_sd21_full_size_infer_defaults_loop",        # infer.py:181-187: 20 steps, guidance 1.0, B = 1
+    "tests/test_engine_gpu.py::test_sd21_full_size_pipeline_defaults_loop_cfg", # pipeline.py defaults: 50 steps, guidance 7.5
 )
 _OUTCOMES = {}
 
