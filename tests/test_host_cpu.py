@@ -227,7 +227,7 @@ def test_headline_parity_tests_cannot_drop_out_of_a_gpu_session():
 
 
 def test_a_gpu_session_whose_headline_tests_skip_exits_nonzero():
-    """The hook end to end: a real pytest session that collects the six headline tests and sees them SKIP (there is no GPU here;
+    """The hook end to end: a real pytest session that collects the headline tests and sees them SKIP (there is no GPU here;
     MVD_ASSUME_GPU_SESSION=1 stands in for one) must end with a non-zero exit status and name the tests; the same selection
     without the stand-in is an ordinary CPU session and passes."""
     import subprocess
